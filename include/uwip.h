@@ -1,0 +1,147 @@
+/*
+ * uwip.h -- C ABI of the MI355X-native (gfx950) implementation of the
+ * uwimageproc per-frame hot path:  bgdehaze -> histretch -> aclahe ->
+ * videostrip-overlap.
+ *
+ * The reference has no FFI/plugin layer: its only seam is ordinary C++ calls
+ * into modules/common/preprocessing.h and modules/videostrip/include/
+ * videostrip.hpp, switched at compile time by USE_GPU and at run time by
+ * -cuda=0/1 (modules/histretch/src/histretch.cpp:72,121-141).  The `...GPU`
+ * twins there (imgChannelStretchGPU, calcOverlapGPU, calcBlurGPU) are the
+ * precedent for an accelerator back end behind the same call sites; this
+ * header is what such a back end binds to.  Every entry point cites the
+ * reference interface it replaces.  INTEGRATION.md shows the reference-side
+ * stubs.
+ *
+ * Conventions
+ *   - plain C: opaque context, raw pointers, sizes; no C++/torch types.
+ *   - every function returns an int status (UWIP_OK == 0); the message for
+ *     the last failure is uwip_last_error(ctx).
+ *   - images are batches of equally sized 8-bit frames in DEVICE memory,
+ *     described by uwip_batch_u8, whose (data, step, rows, cols, channels)
+ *     map field-for-field onto a cv::Mat of type CV_8UC1 / CV_8UC3
+ *     (BGR interleaved, as cv::imread returns).  frames == 1 is one cv::Mat.
+ *   - pointers named d_* are device pointers, h_* host pointers.
+ *   - work is enqueued on the context's HIP stream and is asynchronous
+ *     unless the function has a host-side result; uwip_sync() drains it.
+ *   - there is NO CPU fallback: without a HIP device every compute entry
+ *     point fails with UWIP_ERR_HIP.
+ */
+#ifndef UWIP_H
+#define UWIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UWIP_OK               0
+#define UWIP_ERR_INVALID      1   /* bad argument / shape */
+#define UWIP_ERR_HIP          2   /* HIP runtime failure (incl. no device) */
+#define UWIP_ERR_UNSUPPORTED  3   /* valid request outside the hot path */
+#define UWIP_ERR_NOMEM        4
+
+typedef struct uwip_ctx uwip_ctx;
+
+/* One batch of frames in device memory (cv::Mat fields + batch extent). */
+typedef struct uwip_batch_u8 {
+    void   *data;          /* device pointer: frame 0, row 0 (cv::Mat::data) */
+    size_t  step;          /* bytes between rows (cv::Mat::step)             */
+    size_t  frame_stride;  /* bytes between consecutive frames               */
+    int32_t rows, cols;    /* cv::Mat::rows / cols                           */
+    int32_t channels;      /* 1 (CV_8UC1) or 3 (CV_8UC3, BGR)                */
+    int32_t frames;        /* batch size (1 == a single cv::Mat)             */
+} uwip_batch_u8;
+
+/* ---- context, memory, profiling -------------------------------------- */
+
+/* Replaces cuda::getCudaEnabledDeviceCount / cuda::setDevice(0)
+ * (histretch.cpp:122-134, videostrip/src/main.cpp:188).  `stream` may be a
+ * caller-owned hipStream_t (e.g. the framework's current stream) or NULL to
+ * let the context create its own. */
+int uwip_device_count(int *count);
+int uwip_ctx_create(int device, void *stream, uwip_ctx **out);
+int uwip_ctx_destroy(uwip_ctx *ctx);
+const char *uwip_last_error(const uwip_ctx *ctx);
+const char *uwip_version(void);
+int uwip_sync(uwip_ctx *ctx);
+
+/* Replaces GpuMat::upload / download (histretch.cpp:174-175,212-213). */
+int uwip_malloc(uwip_ctx *ctx, size_t bytes, void **d_ptr);
+int uwip_free(uwip_ctx *ctx, void *d_ptr);
+int uwip_memcpy_h2d(uwip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int uwip_memcpy_d2h(uwip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+/* Per-kernel hipEvent timing on the context's stream (replaces the
+ * getTickCount stopwatch, histretch.cpp:165,257-261).  Enabling it brackets
+ * every kernel launch with events; totals are read back per kernel name. */
+int uwip_prof_enable(uwip_ctx *ctx, int on);
+int uwip_prof_reset(uwip_ctx *ctx);
+int uwip_prof_count(uwip_ctx *ctx, int *n);
+int uwip_prof_get(uwip_ctx *ctx, int index, char *name, size_t name_cap,
+                  double *total_ms, uint64_t *launches);
+
+/* ---- histretch (H1-H4) ------------------------------------------------- */
+
+/* numChannel / numSpace, preprocessing.cpp:147-161 (host, pure). */
+int uwip_numChannel(char c);
+int uwip_numSpace(char c);
+
+/* getHistogram, preprocessing.cpp:25-34 (cv::calcHist, 256 bins), for every
+ * frame and channel of the batch in one pass.  d_hist: [frames][channels][256]
+ * uint32 counts (the reference stores the same counts as CV_32F). */
+int uwip_getHistogram(uwip_ctx *ctx, const uwip_batch_u8 *img, uint32_t *d_hist);
+
+/* Percentile search + stretch LUT, preprocessing.cpp:82-100, for `nplanes`
+ * histograms of rows*cols-pixel planes.  d_lut: [nplanes][256] bytes;
+ * d_bounds (may be NULL): [nplanes][2] int32 = (lower, higher) bins. */
+int uwip_stretch_lut(uwip_ctx *ctx, const uint32_t *d_hist, int nplanes, int rows, int cols,
+                     int lo, int hi, uint8_t *d_lut, int32_t *d_bounds);
+
+/* In-place LUT application (the fused `img += b; img *= m`,
+ * preprocessing.cpp:99-100).  d_lut: [frames][channels][256]. */
+int uwip_apply_lut(uwip_ctx *ctx, const uwip_batch_u8 *img, const uint8_t *d_lut);
+
+/* imgChannelStretch(Mat, Mat, lo, hi), preprocessing.cpp:74-105, on lane
+ * `channel` of every frame, in place (the reference passes the same Mat as
+ * input and output). */
+int uwip_imgChannelStretch(uwip_ctx *ctx, const uwip_batch_u8 *img, int channel, int lo, int hi);
+
+/* The per-letter loop of histretch.cpp:217-254 on BGR frames, in place:
+ * for each letter in order, stretch plane numChannel(letter).  Unknown
+ * letters are skipped as the reference does; colour-space letters (HSV/HLS/
+ * Lab/YCrCb) return UWIP_ERR_UNSUPPORTED (outside the hot path; the
+ * reference discards their result). */
+int uwip_histretch(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi);
+
+/* ---- aclahe (C1-C4) ----------------------------------------------------- */
+
+/* V plane of cvtColor(BGR2HSV)+split, aclahe.cpp:152-154 (V = max(B,G,R)). */
+int uwip_bgr_to_v(uwip_ctx *ctx, const uwip_batch_u8 *bgr, const uwip_batch_u8 *v);
+
+/* cv::CLAHE::{setClipLimit,setTilesGridSize,apply}, aclahe.cpp:184-187, on
+ * 8UC1 planes.  residual_rule: 0 = OpenCV 3.4.x, 1 = OpenCV 3.2. */
+int uwip_clahe(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst,
+               double clipLimit, int gx, int gy, int residual_rule);
+/* Same with per-frame parameters (host arrays of length src->frames), the
+ * "for resulting CL/BS, apply classic clahe" step of aclahe.cpp:215. */
+int uwip_clahe_per_frame(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst,
+                         const double *h_clipLimit, const int32_t *h_grid, int residual_rule);
+/* Tile LUT stage tap for parity tests: d_luts [frames][gy*gx][256]. */
+int uwip_clahe_luts(uwip_ctx *ctx, const uwip_batch_u8 *src, double clipLimit, int gx, int gy,
+                    int residual_rule, uint8_t *d_luts);
+
+/* aclaheEntropy, aclahe.cpp:228-248: d_entropy [frames] float. */
+int uwip_entropy(uwip_ctx *ctx, const uwip_batch_u8 *src, float *d_entropy);
+
+/* The sweep of aclahe.cpp:160-193: grid in {2,4,8,16,32} x clip limit in
+ * {0,0.5,...,25}; d_entropy: [frames][5][51] float (clean table). */
+int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int residual_rule,
+                      float *d_entropy);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UWIP_H */

@@ -1,0 +1,418 @@
+/*
+ * uwip_oracle.c -- CPU restatement of the uwimageproc per-frame hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library, and only as the checker / the timed CPU baseline.  The
+ * shipped path (uwimageproc_amd/libuwip.so) never links or calls it.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference tree).  Arithmetic that lives inside OpenCV 3.x (calcHist,
+ * saturating scalar add, convertTo, cv::CLAHE, cvtColor, Laplacian,
+ * fillConvexPoly ...) is NOT in the reference tree and OpenCV is absent from
+ * the build image, so those parts restate OpenCV 3.4.x's published algorithm
+ * (SURVEY.md Appendix A).  Pinning status per function is stated below;
+ * "parity unpinned" = no reference-held golden vector exists for it (the
+ * reference has no tests at all) and it could not be
+ * diffed against a real OpenCV here.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: the float32
+ * interpolation order of CLAHE must not be fused into FMAs).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ */
+/* helpers                                                             */
+/* ------------------------------------------------------------------ */
+
+/* cv::saturate_cast<uchar>(float) == saturate(cvRound(v)); cvRound is
+ * round-half-to-even (cvtss2si / lrintf in the default rounding mode); NaN and
+ * out-of-range convert to INT_MIN on x86, which then saturates to 0. */
+static inline uint8_t sat_u8_rne(float v)
+{
+    int r;
+    if (!(v == v)) r = INT32_MIN;                         /* NaN */
+    else if (v >= 2147483648.0f || v < -2147483648.0f) r = INT32_MIN;
+    else r = (int)lrintf(v);
+    return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+}
+
+static inline int reflect101(int p, int len)
+{
+    /* cv::BORDER_REFLECT_101: gfedcb|abcdefgh|gfedcba */
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) {
+        if (p < 0) p = -p;
+        else p = 2 * (len - 1) - p;
+    }
+    return p;
+}
+
+/* ------------------------------------------------------------------ */
+/* H3  numChannel / numSpace   modules/common/preprocessing.cpp:147-161 */
+/* ------------------------------------------------------------------ */
+ORC_API int orc_numChannel(char c)
+{
+    if (c == 'R' || c == 'H' || c == 'h' || c == 'L' || c == 'Y') return 0;
+    if (c == 'G' || c == 'S' || c == 's' || c == 'a' || c == 'C') return 1;
+    if (c == 'B' || c == 'V' || c == 'l' || c == 'b' || c == 'X') return 2;
+    return -1;
+}
+
+ORC_API int orc_numSpace(char c)
+{
+    if (c == 'R' || c == 'G' || c == 'B') return 0;
+    if (c == 'H' || c == 'S' || c == 'V') return 1;
+    if (c == 'h' || c == 's' || c == 'l') return 2;
+    if (c == 'L' || c == 'a' || c == 'b') return 3;
+    if (c == 'Y' || c == 'C' || c == 'X') return 4;
+    return -1;
+}
+
+/* ------------------------------------------------------------------ */
+/* H1  getHistogram   modules/common/preprocessing.cpp:25-34            */
+/*     cv::calcHist, 256 uniform bins over [0,256), CV_32F counts.      */
+/*     `pix` = byte distance between consecutive samples of the plane   */
+/*     (1 for a split plane, 3 for one lane of packed BGR).             */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_getHistogram(const uint8_t *data, int rows, int cols, size_t step,
+                              int pix, float hist[256])
+{
+    uint32_t h[256];
+    memset(h, 0, sizeof h);
+    for (int y = 0; y < rows; ++y) {
+        const uint8_t *p = data + (size_t)y * step;
+        for (int x = 0; x < cols; ++x) h[p[(size_t)x * pix]]++;
+    }
+    for (int i = 0; i < 256; ++i) hist[i] = (float)h[i];
+}
+
+/* ------------------------------------------------------------------ */
+/* H2  percentile search + LUT  modules/common/preprocessing.cpp:82-100 */
+/*     All float32 exactly as written there.  The two in-place ops       */
+/*     `img += b` (saturating integer add, b integral) and `img *= m`    */
+/*     (convertTo: sat_u8(rne(v*m))) compose into one 256-entry LUT.     */
+/*     The while loop is bounded at 256 bins (the reference would read   */
+/*     past the histogram if hi*norm rounds above the pixel count).      */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_stretch_lut(const float hist[256], int rows, int cols, int lo, int hi,
+                             uint8_t lut[256], int *lower_out, int *higher_out)
+{
+    float channelLowerPercentile = -1.0f, channelHigherPercentile = -1.0f;
+    int i = 0;
+    float sum = 0.0f;
+    float normImgSize = (float)((double)(rows * cols) / 100.0);   /* :87 */
+    while (sum < (float)hi * normImgSize && i < 256) {            /* :89 */
+        if (sum < (float)lo * normImgSize) channelLowerPercentile += 1.0f;
+        channelHigherPercentile += 1.0f;
+        sum += hist[i];
+        i++;
+    }
+    float b = -channelLowerPercentile;                                             /* :96 */
+    float m = (float)(255.0 / ((double)channelHigherPercentile - (double)channelLowerPercentile)); /* :97 */
+    for (int v = 0; v < 256; ++v) {
+        int a = v + (int)b;                 /* :99  cv::add with an integral scalar, saturating */
+        uint8_t s = (uint8_t)(a < 0 ? 0 : (a > 255 ? 255 : a));
+        lut[v] = sat_u8_rne((float)s * m);  /* :100 convertTo(alpha=m) */
+    }
+    if (lower_out) *lower_out = (int)channelLowerPercentile;
+    if (higher_out) *higher_out = (int)channelHigherPercentile;
+}
+
+/* H2 whole function: in-place stretch of ONE plane (imgOriginal and
+ * imgStretched share data, as every reference call site passes the same Mat). */
+ORC_API void orc_imgChannelStretch(uint8_t *data, int rows, int cols, size_t step, int pix,
+                                   int lo, int hi)
+{
+    float hist[256];
+    uint8_t lut[256];
+    orc_getHistogram(data, rows, cols, step, pix, hist);
+    orc_stretch_lut(hist, rows, cols, lo, hi, lut, NULL, NULL);
+    for (int y = 0; y < rows; ++y) {
+        uint8_t *p = data + (size_t)y * step;
+        for (int x = 0; x < cols; ++x) p[(size_t)x * pix] = lut[p[(size_t)x * pix]];
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* H4  histretch per-letter loop  modules/histretch/src/histretch.cpp:217-254
+ *     BGR letters (space 0): split / stretch plane numChannel(c) / merge,
+ *     i.e. an in-place stretch of one lane of the packed image, letters in
+ *     order.  Unknown letters are skipped (:252).  Colour-space letters
+ *     (space 1-4) are out of the hot path (the reference
+ *     discards their result); they return 1 here so callers can tell.       */
+/* ------------------------------------------------------------------ */
+ORC_API int orc_histretch_bgr(uint8_t *img, int rows, int cols, size_t step,
+                              const char *letters, int lo, int hi)
+{
+    int unsupported = 0;
+    for (const char *c = letters; *c; ++c) {
+        int ch = orc_numChannel(*c), sp = orc_numSpace(*c);
+        if (sp == -1) continue;
+        if (sp != 0) { unsupported = 1; continue; }
+        orc_imgChannelStretch(img + ch, rows, cols, step, 3, lo, hi);
+    }
+    return unsupported;
+}
+
+/* ------------------------------------------------------------------ */
+/* V plane of 8-bit HSV == max(B,G,R) exactly (cvtColor BGR2HSV, 8U),     */
+/* used by modules/aclahe/src/aclahe.cpp:152-154 (channels[2]).           */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_bgr_to_v(const uint8_t *bgr, int rows, int cols, size_t step,
+                          uint8_t *v, size_t vstep)
+{
+    for (int y = 0; y < rows; ++y) {
+        const uint8_t *p = bgr + (size_t)y * step;
+        uint8_t *q = v + (size_t)y * vstep;
+        for (int x = 0; x < cols; ++x) {
+            uint8_t b = p[3 * x], g = p[3 * x + 1], r = p[3 * x + 2];
+            uint8_t m = b > g ? b : g;
+            q[x] = m > r ? m : r;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* C1  cv::CLAHE::apply, 8-bit, as driven by
+ *     modules/aclahe/src/aclahe.cpp:175-187.  Restates OpenCV 3.4.x
+ *     imgproc/src/clahe.cpp.  parity unpinned:
+ *     no reference-held vector; checked only against hand-computed cases.
+ *     residual_rule: 0 = OpenCV 3.4.x (strided), 1 = OpenCV 3.2 (first bins).
+ *     Scratch LUT storage is returned through `luts` when non-NULL
+ *     (gy*gx*256 bytes) so tests can compare the tile LUT stage too.       */
+/* ------------------------------------------------------------------ */
+ORC_API int orc_clahe_tile_geometry(int rows, int cols, int gx, int gy, int *tw, int *th,
+                                    int *padded_cols, int *padded_rows)
+{
+    int pc = cols, pr = rows;
+    if (!(cols % gx == 0 && rows % gy == 0)) {
+        pr = rows + (gy - (rows % gy));
+        pc = cols + (gx - (cols % gx));
+    }
+    *tw = pc / gx; *th = pr / gy; *padded_cols = pc; *padded_rows = pr;
+    return 0;
+}
+
+ORC_API void orc_clahe_make_lut(const int32_t hist_in[256], int tile_area, int clip,
+                                int residual_rule, uint8_t lut[256])
+{
+    int32_t h[256];
+    memcpy(h, hist_in, sizeof h);
+    if (clip > 0) {
+        int clipped = 0;
+        for (int i = 0; i < 256; ++i)
+            if (h[i] > clip) { clipped += h[i] - clip; h[i] = clip; }
+        int batch = clipped / 256;
+        int residual = clipped - batch * 256;
+        for (int i = 0; i < 256; ++i) h[i] += batch;
+        if (residual != 0) {
+            if (residual_rule == 0) {
+                int stepr = 256 / residual; if (stepr < 1) stepr = 1;
+                for (int i = 0; i < 256 && residual > 0; i += stepr, residual--) h[i]++;
+            } else {
+                for (int i = 0; i < residual; ++i) h[i]++;
+            }
+        }
+    }
+    const float lutScale = (float)255 / (float)tile_area;
+    int sum = 0;
+    for (int i = 0; i < 256; ++i) {
+        sum += h[i];
+        lut[i] = sat_u8_rne((float)sum * lutScale);
+    }
+}
+
+ORC_API int orc_clahe_clip_from_limit(double clipLimit, int tile_area)
+{
+    int clip = 0;
+    if (clipLimit > 0.0) {
+        clip = (int)(clipLimit * tile_area / 256);
+        if (clip < 1) clip = 1;
+    }
+    return clip;
+}
+
+ORC_API void orc_clahe_tile_hists(const uint8_t *src, int rows, int cols, size_t step,
+                                  int gx, int gy, int32_t *hists /* gy*gx*256 */)
+{
+    int tw, th, pc, pr;
+    orc_clahe_tile_geometry(rows, cols, gx, gy, &tw, &th, &pc, &pr);
+    memset(hists, 0, sizeof(int32_t) * 256 * (size_t)gx * gy);
+    for (int y = 0; y < pr; ++y) {
+        const uint8_t *row = src + (size_t)reflect101(y, rows) * step;
+        int ty = y / th;
+        for (int x = 0; x < pc; ++x) {
+            int tx = x / tw;
+            hists[((size_t)ty * gx + tx) * 256 + row[reflect101(x, cols)]]++;
+        }
+    }
+}
+
+ORC_API void orc_clahe_interpolate(const uint8_t *src, int rows, int cols, size_t step,
+                                   uint8_t *dst, size_t dstep, const uint8_t *luts,
+                                   int gx, int gy, int tw, int th)
+{
+    const float inv_tw = 1.0f / (float)tw;
+    const float inv_th = 1.0f / (float)th;
+    for (int y = 0; y < rows; ++y) {
+        float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf);
+        int ty2 = ty1 + 1;
+        float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+        if (ty1 < 0) ty1 = 0;
+        if (ty2 > gy - 1) ty2 = gy - 1;
+        const uint8_t *p1 = luts + (size_t)ty1 * gx * 256;
+        const uint8_t *p2 = luts + (size_t)ty2 * gx * 256;
+        const uint8_t *s = src + (size_t)y * step;
+        uint8_t *d = dst + (size_t)y * dstep;
+        for (int x = 0; x < cols; ++x) {
+            float txf = (float)x * inv_tw - 0.5f;
+            int tx1 = (int)floorf(txf);
+            int tx2 = tx1 + 1;
+            float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+            if (tx1 < 0) tx1 = 0;
+            if (tx2 > gx - 1) tx2 = gx - 1;
+            int v = s[x];
+            float a = (float)p1[tx1 * 256 + v], b = (float)p1[tx2 * 256 + v];
+            float c = (float)p2[tx1 * 256 + v], e = (float)p2[tx2 * 256 + v];
+            float res = (a * xa1 + b * xa) * ya1 + (c * xa1 + e * xa) * ya;
+            d[x] = sat_u8_rne(res);
+        }
+    }
+}
+
+ORC_API int orc_clahe_u8(const uint8_t *src, int rows, int cols, size_t step, uint8_t *dst,
+                         size_t dstep, double clipLimit, int gx, int gy, int residual_rule,
+                         uint8_t *luts_out /* may be NULL */)
+{
+    int tw, th, pc, pr;
+    orc_clahe_tile_geometry(rows, cols, gx, gy, &tw, &th, &pc, &pr);
+    int area = tw * th;
+    int clip = orc_clahe_clip_from_limit(clipLimit, area);
+    int32_t *hists = (int32_t *)malloc(sizeof(int32_t) * 256 * (size_t)gx * gy);
+    uint8_t *luts = (uint8_t *)malloc((size_t)256 * gx * gy);
+    if (!hists || !luts) { free(hists); free(luts); return -1; }
+    orc_clahe_tile_hists(src, rows, cols, step, gx, gy, hists);
+    for (int t = 0; t < gx * gy; ++t)
+        orc_clahe_make_lut(hists + (size_t)t * 256, area, clip, residual_rule, luts + (size_t)t * 256);
+    orc_clahe_interpolate(src, rows, cols, step, dst, dstep, luts, gx, gy, tw, th);
+    if (luts_out) memcpy(luts_out, luts, (size_t)256 * gx * gy);
+    free(hists); free(luts);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* C2  aclaheEntropy   modules/aclahe/src/aclahe.cpp:228-248            */
+/*     p = hist/(W*H) in f32; each term in double; running sum rounded  */
+/*     back to f32 every step; result negated.                          */
+/* ------------------------------------------------------------------ */
+ORC_API float orc_entropy_from_hist(const float hist[256], int rows, int cols)
+{
+    float entropy = 0;
+    float histN[256];
+    for (int i = 0; i < 256; ++i) {
+        histN[i] = hist[i] / (float)(cols * rows);
+        entropy = (float)((double)entropy + ((double)histN[i] * log2((double)histN[i] + 0.00001)));
+    }
+    return -entropy;
+}
+
+ORC_API float orc_aclaheEntropy(const uint8_t *img, int rows, int cols, size_t step)
+{
+    float hist[256];
+    orc_getHistogram(img, rows, cols, step, 1, hist);
+    return orc_entropy_from_hist(hist, rows, cols);
+}
+
+/* ------------------------------------------------------------------ */
+/* C3  sweep driver   modules/aclahe/src/aclahe.cpp:160-193             */
+/*     grid in {2,4,8,16,32} x cl in {0,0.5,...,25} (float loop, 51      */
+/*     values) on one 8-bit plane (V).  Emits a clean 5x51 table         */
+/*     (the reference's printed rows are cumulative).     */
+/* ------------------------------------------------------------------ */
+ORC_API int orc_aclahe_sweep(const uint8_t *plane, int rows, int cols, size_t step,
+                             int residual_rule, float out[5 * 51])
+{
+    static const int BlockSize[5] = {2, 4, 8, 16, 32};
+    uint8_t *dst = (uint8_t *)malloc((size_t)rows * cols);
+    if (!dst) return -1;
+    for (int i = 0; i < 5; ++i) {
+        int g = BlockSize[i];
+        int tw, th, pc, pr;
+        orc_clahe_tile_geometry(rows, cols, g, g, &tw, &th, &pc, &pr);
+        int area = tw * th;
+        int32_t *hists = (int32_t *)malloc(sizeof(int32_t) * 256 * (size_t)g * g);
+        uint8_t *luts = (uint8_t *)malloc((size_t)256 * g * g);
+        orc_clahe_tile_hists(plane, rows, cols, step, g, g, hists);
+        int j = 0;
+        for (float cl = 0.0f; cl <= 25.0f; cl += 0.5f, ++j) {
+            int clip = orc_clahe_clip_from_limit((double)cl, area);
+            for (int t = 0; t < g * g; ++t)
+                orc_clahe_make_lut(hists + (size_t)t * 256, area, clip, residual_rule,
+                                   luts + (size_t)t * 256);
+            orc_clahe_interpolate(plane, rows, cols, step, dst, (size_t)cols, luts, g, g, tw, th);
+            out[i * 51 + j] = orc_aclaheEntropy(dst, rows, cols, (size_t)cols);
+        }
+        free(hists); free(luts);
+    }
+    free(dst);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* BGR -> gray, 8-bit (cv::cvtColor COLOR_BGR2GRAY, OpenCV 3.x fixed     */
+/* point: (B*1868 + G*9617 + R*4899 + 8192) >> 14).  Used by            */
+/* modules/videostrip/src/videostrip.cpp:173,202.  parity unpinned.      */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_bgr_to_gray(const uint8_t *bgr, int rows, int cols, size_t step,
+                             uint8_t *gray, size_t gstep)
+{
+    for (int y = 0; y < rows; ++y) {
+        const uint8_t *p = bgr + (size_t)y * step;
+        uint8_t *q = gray + (size_t)y * gstep;
+        for (int x = 0; x < cols; ++x)
+            q[x] = (uint8_t)((p[3 * x] * 1868 + p[3 * x + 1] * 9617 + p[3 * x + 2] * 4899 + 8192) >> 14);
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* V5  calcBlur   modules/videostrip/src/videostrip.cpp:170-184          */
+/*     gray -> Laplacian(ddepth = grey.type() = CV_8U, ksize = CV_16S =   */
+/*     3): aperture-3 Laplacian kernel [2 0 2; 0 -8 0; 2 0 2], border    */
+/*     REFLECT_101, saturated to u8; returns the population stddev.       */
+/*     parity unpinned (OpenCV-internal kernel).           */
+/* ------------------------------------------------------------------ */
+ORC_API double orc_laplacian_stddev_gray(const uint8_t *g, int rows, int cols, size_t step)
+{
+    double s = 0, s2 = 0;
+    for (int y = 0; y < rows; ++y) {
+        const uint8_t *r0 = g + (size_t)reflect101(y - 1, rows) * step;
+        const uint8_t *r1 = g + (size_t)y * step;
+        const uint8_t *r2 = g + (size_t)reflect101(y + 1, rows) * step;
+        for (int x = 0; x < cols; ++x) {
+            int xm = reflect101(x - 1, cols), xp = reflect101(x + 1, cols);
+            int v = 2 * (r0[xm] + r0[xp] + r2[xm] + r2[xp]) - 8 * r1[x];
+            v = v < 0 ? 0 : (v > 255 ? 255 : v);
+            s += v; s2 += (double)v * v;
+        }
+    }
+    double n = (double)rows * cols;
+    double mean = s / n;
+    double var = s2 / n - mean * mean;
+    return sqrt(var < 0 ? 0 : var);
+}
+
+ORC_API float orc_calcBlur(const uint8_t *bgr, int rows, int cols, size_t step)
+{
+    uint8_t *gray = (uint8_t *)malloc((size_t)rows * cols);
+    orc_bgr_to_gray(bgr, rows, cols, step, gray, (size_t)cols);
+    float r = (float)orc_laplacian_stddev_gray(gray, rows, cols, (size_t)cols);
+    free(gray);
+    return r;
+}

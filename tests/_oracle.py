@@ -1,0 +1,130 @@
+"""ctypes binding of oracle/liboracle.so for the tests (the oracle is the
+checker, never the product).  Builds it with oracle/Makefile when missing."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+u8p = np.ctypeslib.ndpointer(dtype=np.uint8, flags="C_CONTIGUOUS")
+f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        L = lib
+        L.orc_numChannel.restype = C.c_int; L.orc_numChannel.argtypes = [C.c_char]
+        L.orc_numSpace.restype = C.c_int; L.orc_numSpace.argtypes = [C.c_char]
+        L.orc_getHistogram.restype = None
+        L.orc_getHistogram.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, f32p]
+        L.orc_stretch_lut.restype = None
+        L.orc_stretch_lut.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_int, u8p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_histretch_bgr.restype = C.c_int
+        L.orc_histretch_bgr.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_char_p, C.c_int, C.c_int]
+        L.orc_imgChannelStretch.restype = None
+        L.orc_imgChannelStretch.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        L.orc_bgr_to_v.restype = None
+        L.orc_bgr_to_v.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t]
+        L.orc_clahe_u8.restype = C.c_int
+        L.orc_clahe_u8.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.orc_clahe_tile_geometry.restype = C.c_int
+        L.orc_clahe_tile_geometry.argtypes = [C.c_int] * 4 + [C.POINTER(C.c_int)] * 4
+        L.orc_aclaheEntropy.restype = C.c_float
+        L.orc_aclaheEntropy.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t]
+        L.orc_aclahe_sweep.restype = C.c_int
+        L.orc_aclahe_sweep.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, f32p]
+        L.orc_bgr_to_gray.restype = None
+        L.orc_bgr_to_gray.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t]
+        L.orc_calcBlur.restype = C.c_float
+        L.orc_calcBlur.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t]
+
+    # ---- numpy-friendly wrappers ----
+    def numChannel(self, c): return self.lib.orc_numChannel(c.encode()[:1])
+    def numSpace(self, c): return self.lib.orc_numSpace(c.encode()[:1])
+
+    def getHistogram(self, plane):
+        """plane: HxW uint8 view (any strides along rows; pixel stride = last stride)."""
+        assert plane.dtype == np.uint8 and plane.ndim == 2
+        out = np.zeros(256, np.float32)
+        self.lib.orc_getHistogram(plane.ctypes.data, plane.shape[0], plane.shape[1],
+                                  plane.strides[0], plane.strides[1], out)
+        return out
+
+    def stretch_lut(self, hist, rows, cols, lo, hi):
+        lut = np.zeros(256, np.uint8)
+        a, b = C.c_int(0), C.c_int(0)
+        self.lib.orc_stretch_lut(np.ascontiguousarray(hist, np.float32), rows, cols, lo, hi, lut, C.byref(a), C.byref(b))
+        return lut, a.value, b.value
+
+    def histretch(self, img, letters, lo=2, hi=98):
+        out = np.ascontiguousarray(img).copy()
+        rc = self.lib.orc_histretch_bgr(out, out.shape[0], out.shape[1], out.strides[0], letters.encode(), lo, hi)
+        return out, rc
+
+    def imgChannelStretch(self, plane, lo, hi):
+        """in place on a 2-D uint8 view"""
+        self.lib.orc_imgChannelStretch(plane.ctypes.data, plane.shape[0], plane.shape[1], plane.strides[0], plane.strides[1], lo, hi)
+
+    def bgr_to_v(self, img):
+        img = np.ascontiguousarray(img)
+        v = np.zeros(img.shape[:2], np.uint8)
+        self.lib.orc_bgr_to_v(img, img.shape[0], img.shape[1], img.strides[0], v, v.strides[0])
+        return v
+
+    def clahe(self, plane, clip, gx, gy, rule=0, want_luts=False):
+        plane = np.ascontiguousarray(plane)
+        dst = np.zeros_like(plane)
+        luts = np.zeros((gy * gx, 256), np.uint8)
+        rc = self.lib.orc_clahe_u8(plane, plane.shape[0], plane.shape[1], plane.strides[0], dst, dst.strides[0],
+                                   float(clip), gx, gy, rule, luts.ctypes.data)
+        assert rc == 0
+        return (dst, luts) if want_luts else dst
+
+    def tile_geometry(self, rows, cols, gx, gy):
+        v = [C.c_int(0) for _ in range(4)]
+        self.lib.orc_clahe_tile_geometry(rows, cols, gx, gy, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)  # tw, th, padded_cols, padded_rows
+
+    def entropy(self, plane):
+        plane = np.ascontiguousarray(plane)
+        return float(self.lib.orc_aclaheEntropy(plane, plane.shape[0], plane.shape[1], plane.strides[0]))
+
+    def sweep(self, plane, rule=0):
+        plane = np.ascontiguousarray(plane)
+        out = np.zeros(5 * 51, np.float32)
+        rc = self.lib.orc_aclahe_sweep(plane, plane.shape[0], plane.shape[1], plane.strides[0], rule, out)
+        assert rc == 0
+        return out.reshape(5, 51)
+
+    def bgr_to_gray(self, img):
+        img = np.ascontiguousarray(img)
+        g = np.zeros(img.shape[:2], np.uint8)
+        self.lib.orc_bgr_to_gray(img, img.shape[0], img.shape[1], img.strides[0], g, g.strides[0])
+        return g
+
+    def calcBlur(self, img):
+        img = np.ascontiguousarray(img)
+        return float(self.lib.orc_calcBlur(img, img.shape[0], img.shape[1], img.strides[0]))
+
+
+_cached = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def load():
+    global _cached
+    if _cached is None:
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith(".c")]
+        if (not os.path.exists(LIB)) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+            build()
+        _cached = Oracle(C.CDLL(LIB))
+    return _cached

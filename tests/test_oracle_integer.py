@@ -1,0 +1,247 @@
+"""CPU: pin the C oracle's integer stages against hand-computed known answers
+and an independent pure-numpy restatement (small cases).  The reference holds
+no golden vectors for these stages, so these literal
+numbers are the pin; bit-exactness vs a real OpenCV 3.4.6 remains unconfirmed
+("parity unpinned" in DESIGN.md)."""
+import numpy as np
+import pytest
+
+from uwimageproc_amd import synth
+
+
+def test_numChannel_numSpace(orc):
+    # preprocessing.cpp:147-161 -- including the R->plane 0 (blue) quirk
+    assert [orc.numChannel(c) for c in "RGBHSVhslLabYCX"] == [0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1, 2]
+    assert [orc.numSpace(c) for c in "RGBHSVhslLabYCX"] == [0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3, 4, 4, 4]
+    assert orc.numChannel("r") == -1 and orc.numSpace("r") == -1   # default -c=r is a no-op (B-1)
+
+
+def test_histogram_known(orc):
+    p = np.array([[0, 0, 1, 255], [7, 7, 7, 7], [1, 2, 3, 4], [255, 255, 0, 9]], np.uint8)
+    h = orc.getHistogram(p)
+    exp = np.zeros(256, np.float32)
+    for v in p.ravel():
+        exp[v] += 1
+    assert np.array_equal(h, exp)
+    assert h[0] == 3 and h[7] == 4 and h[255] == 3 and h.sum() == 16
+
+
+def test_stretch_lut_hand_case(orc):
+    # 10x10 plane: norm = 1.0, thresholds 2 and 98.
+    hist = np.zeros(256, np.float32)
+    hist[10], hist[20], hist[30], hist[200] = 1, 1, 96, 2
+    lut, lower, higher = orc.stretch_lut(hist, 10, 10, 2, 98)
+    assert (lower, higher) == (20, 30)            # derived by stepping the loop by hand
+    # m = 25.5: ties round to even
+    assert lut[20] == 0 and lut[21] == 26 and lut[23] == 76 and lut[25] == 128 and lut[30] == 255
+    assert lut[0] == 0 and lut[19] == 0 and lut[31] == 255 and lut[255] == 255
+
+
+def test_stretch_degenerate_plane_is_zero(orc):
+    # >= 98 % of pixels in one bin -> higher == lower -> m = inf -> all zeros (A-2)
+    img = synth.adversarial("constant", 12, 20)
+    out, rc = orc.histretch(img, "RGB")
+    assert rc == 0 and out.max() == 0
+
+
+def test_stretch_lo0_hi100(orc):
+    # preprocessing.h defaults 0/100: lower stays -1 (b = +1)
+    rng = np.random.default_rng(3)
+    p = rng.integers(0, 256, (20, 20), dtype=np.uint8)
+    hist = orc.getHistogram(p)
+    lut, lower, higher = orc.stretch_lut(hist, 20, 20, 0, 100)
+    assert lower == -1
+    assert higher == int(np.nonzero(np.cumsum(hist) >= 400.0)[0][0])
+
+
+def _np_stretch_plane(p, lo, hi):
+    """independent numpy restatement of preprocessing.cpp:82-100"""
+    rows, cols = p.shape
+    hist = np.bincount(p.ravel(), minlength=256).astype(np.float32)
+    norm = np.float32(rows * cols / 100.0)
+    lower = higher = np.float32(-1)
+    s = np.float32(0)
+    i = 0
+    while s < np.float32(hi) * norm and i < 256:
+        if s < np.float32(lo) * norm:
+            lower += np.float32(1)
+        higher += np.float32(1)
+        s = np.float32(s + hist[i])
+        i += 1
+    with np.errstate(divide="ignore", invalid="ignore"):
+        m = np.float32(255.0 / (float(higher) - float(lower)))
+        a = np.clip(p.astype(np.int32) - int(lower), 0, 255).astype(np.float32)
+        r = a * m
+        r = np.where(np.isfinite(r), r, -1.0)     # NaN/inf -> INT_MIN -> 0
+        return np.clip(np.rint(r), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("kind", ["uw", "random", "two_level", "ramp"])
+def test_histretch_matches_numpy(orc, kind):
+    img = synth.uw_frame(0, 48, 64) if kind == "uw" else synth.adversarial(kind, 48, 64)
+    out, rc = orc.histretch(img, "RGB")
+    exp = img.copy()
+    for c in range(3):
+        exp[..., c] = _np_stretch_plane(img[..., c], 2, 98)
+    assert rc == 0 and np.array_equal(out, exp)
+
+
+def test_histretch_letter_quirks(orc):
+    img = synth.uw_frame(1, 32, 40)
+    # -c=R stretches plane 0 (blue) of the BGR image (B-2)
+    out, _ = orc.histretch(img, "R")
+    assert np.array_equal(out[..., 1:], img[..., 1:]) and not np.array_equal(out[..., 0], img[..., 0])
+    # default "r" and unknown letters are skipped (B-1)
+    out, rc = orc.histretch(img, "r?z")
+    assert rc == 0 and np.array_equal(out, img)
+    # repeated letter = stretch twice
+    once, _ = orc.histretch(img, "G")
+    twice, _ = orc.histretch(img, "GG")
+    again, _ = orc.histretch(once, "G")
+    assert np.array_equal(twice, again)
+    # colour-space letters are flagged (outside the hot path)
+    _, rc = orc.histretch(img, "V")
+    assert rc == 1
+
+
+# ---------------------------------------------------------------- CLAHE ----
+def _np_clahe(src, clip_limit, gx, gy, rule=0):
+    """independent pure-numpy/python restatement of cv::CLAHE (A-3), small inputs only"""
+    rows, cols = src.shape
+    if cols % gx == 0 and rows % gy == 0:
+        ext = src
+    else:
+        ext = np.pad(src, ((0, gy - rows % gy), (0, gx - cols % gx)), mode="reflect")
+    th, tw = ext.shape[0] // gy, ext.shape[1] // gx
+    area = tw * th
+    clip = 0
+    if clip_limit > 0:
+        clip = max(int(clip_limit * area / 256), 1)
+    scale = np.float32(255) / np.float32(area)
+    luts = np.zeros((gy, gx, 256), np.uint8)
+    for ty in range(gy):
+        for tx in range(gx):
+            h = np.bincount(ext[ty * th:(ty + 1) * th, tx * tw:(tx + 1) * tw].ravel(), minlength=256).astype(np.int64)
+            if clip > 0:
+                clipped = int(np.maximum(h - clip, 0).sum())
+                h = np.minimum(h, clip)
+                batch, residual = divmod(clipped, 256)
+                h += batch
+                if residual:
+                    if rule == 0:
+                        step = max(256 // residual, 1)
+                        i = 0
+                        while i < 256 and residual > 0:
+                            h[i] += 1
+                            i += step
+                            residual -= 1
+                    else:
+                        h[:residual] += 1
+            cs = np.cumsum(h).astype(np.float32) * scale
+            luts[ty, tx] = np.clip(np.rint(cs), 0, 255).astype(np.uint8)
+    out = np.zeros_like(src)
+    inv_tw, inv_th = np.float32(1.0) / np.float32(tw), np.float32(1.0) / np.float32(th)
+    for y in range(rows):
+        tyf = np.float32(y) * inv_th - np.float32(0.5)
+        ty1 = int(np.floor(tyf)); ty2 = ty1 + 1
+        ya = np.float32(tyf - np.float32(ty1)); ya1 = np.float32(1.0) - ya
+        ty1 = max(ty1, 0); ty2 = min(ty2, gy - 1)
+        for x in range(cols):
+            txf = np.float32(x) * inv_tw - np.float32(0.5)
+            tx1 = int(np.floor(txf)); tx2 = tx1 + 1
+            xa = np.float32(txf - np.float32(tx1)); xa1 = np.float32(1.0) - xa
+            tx1 = max(tx1, 0); tx2 = min(tx2, gx - 1)
+            v = src[y, x]
+            a, b = np.float32(luts[ty1, tx1, v]), np.float32(luts[ty1, tx2, v])
+            c, d = np.float32(luts[ty2, tx1, v]), np.float32(luts[ty2, tx2, v])
+            res = np.float32(np.float32(np.float32(a * xa1) + np.float32(b * xa)) * ya1) + \
+                np.float32(np.float32(np.float32(c * xa1) + np.float32(d * xa)) * ya)
+            out[y, x] = np.uint8(min(max(int(np.rint(np.float32(res))), 0), 255))
+    return out, luts.reshape(gy * gx, 256)
+
+
+def test_clahe_tile_geometry(orc):
+    # 1080p tile sizes, both pads applied when either dim fails to divide
+    assert orc.tile_geometry(1080, 1920, 2, 2)[:2] == (960, 540)
+    assert orc.tile_geometry(1080, 1920, 8, 8)[:2] == (240, 135)
+    assert orc.tile_geometry(1080, 1920, 16, 16) == (121, 68, 1936, 1088)
+    assert orc.tile_geometry(1080, 1920, 32, 32) == (61, 34, 1952, 1088)
+    assert orc.tile_geometry(2160, 3840, 32, 32) == (121, 68, 3872, 2176)
+
+
+def test_clahe_hand_case_no_clip(orc):
+    # 4x4, 2x2 tiles of 2x2 pixels, clip 0: lut = rne(cumsum * 63.75)
+    src = np.array([[0, 1, 10, 10], [1, 1, 10, 20], [5, 5, 7, 7], [5, 6, 7, 7]], np.uint8)
+    dst, luts = orc.clahe(src, 0.0, 2, 2, want_luts=True)
+    # tile (0,0) = {0,1,1,1}: cum(0)=1 -> 63.75 -> 64 ; cum(1)=4 -> 255
+    assert luts[0][0] == 64 and luts[0][1] == 255 and luts[0][255] == 255
+    # tile (0,1) = {10,10,10,20}: below 10 -> 0 ; 10 -> 3*63.75=191.25 -> 191 ; >=20 -> 255
+    assert luts[1][9] == 0 and luts[1][10] == 191 and luts[1][19] == 191 and luts[1][20] == 255
+    # corner pixel (0,0): txf=tyf=-0.5 -> both neighbours clamp to tile (0,0): res = lut00[0] = 64
+    assert dst[0, 0] == 64
+    # pixel (0,3) value 10: x: txf = 3*0.5-0.5 = 1.0 -> tx1=1, xa=0 -> tile column 1 only; y clamps to row 0
+    assert dst[0, 3] == 191
+    exp, exp_luts = _np_clahe(src, 0.0, 2, 2)
+    assert np.array_equal(luts, exp_luts) and np.array_equal(dst, exp)
+
+
+@pytest.mark.parametrize("shape,grid,clip,rule", [
+    ((32, 48), (2, 2), 0.0, 0), ((32, 48), (4, 4), 2.0, 0), ((30, 50), (4, 4), 3.5, 0),
+    ((37, 53), (8, 8), 40.0, 0), ((37, 53), (8, 8), 1.0, 1), ((24, 24), (3, 5), 4.0, 0),
+    ((64, 64), (16, 16), 0.5, 0),
+])
+def test_clahe_matches_numpy(orc, shape, grid, clip, rule):
+    img = synth.uw_frame(5, shape[0], shape[1])
+    src = orc.bgr_to_v(img)
+    dst, luts = orc.clahe(src, clip, grid[0], grid[1], rule, want_luts=True)
+    exp, exp_luts = _np_clahe(src, clip, grid[0], grid[1], rule)
+    assert np.array_equal(luts, exp_luts)
+    assert np.array_equal(dst, exp)
+
+
+def test_clahe_residual_rules_differ_only_in_residual_bins(orc):
+    rng = np.random.default_rng(1)
+    src = rng.integers(0, 40, (32, 32), dtype=np.uint8)
+    _, l0 = orc.clahe(src, 1.0, 2, 2, 0, want_luts=True)
+    _, l1 = orc.clahe(src, 1.0, 2, 2, 1, want_luts=True)
+    assert l0.shape == l1.shape and (l0[:, 255] == 255).all() and (l1[:, 255] == 255).all()
+
+
+def test_bgr_to_v_is_max(orc):
+    img = synth.adversarial("random", 17, 23)
+    assert np.array_equal(orc.bgr_to_v(img), img.max(axis=2))
+
+
+def test_entropy_known(orc):
+    # uniform over 4 grey levels -> -(4 * 0.25*log2(0.25+1e-5)) ~= 2 - tiny
+    p = np.repeat(np.array([0, 1, 2, 3], np.uint8), 16).reshape(8, 8)
+    e = orc.entropy(p)
+    exp = -4 * 0.25 * np.log2(0.25 + 1e-5)
+    assert abs(e - exp) < 1e-6
+    # constant image -> -(1*log2(1+1e-5)) ~= -1.44e-5
+    assert abs(orc.entropy(np.full((8, 8), 9, np.uint8)) - (-np.log2(1 + 1e-5))) < 1e-6
+
+
+def test_sweep_table_shape_and_cl0(orc):
+    img = synth.uw_frame(2, 64, 96)
+    v = orc.bgr_to_v(img)
+    tab = orc.sweep(v)
+    assert tab.shape == (5, 51)
+    # each entry equals entropy(CLAHE(grid, cl)) -- spot-check a few
+    for gi, g in enumerate((2, 4, 8, 16, 32)):
+        for ci in (0, 1, 17, 50):
+            e = orc.entropy(orc.clahe(v, 0.5 * ci, g, g))
+            assert tab[gi, ci] == np.float32(e)
+
+
+def test_gray_and_blur(orc):
+    img = synth.uw_frame(3, 36, 64)
+    g = orc.bgr_to_gray(img)
+    exp = ((img[..., 0].astype(np.int64) * 1868 + img[..., 1].astype(np.int64) * 9617 + img[..., 2].astype(np.int64) * 4899 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(g, exp)
+    # Laplacian aperture 3 -> kernel [2 0 2; 0 -8 0; 2 0 2], REFLECT_101, saturate to u8
+    gp = np.pad(g.astype(np.int64), 1, mode="reflect")
+    lap = 2 * (gp[:-2, :-2] + gp[:-2, 2:] + gp[2:, :-2] + gp[2:, 2:]) - 8 * gp[1:-1, 1:-1]
+    lap = np.clip(lap, 0, 255).astype(np.float64)
+    assert abs(orc.calcBlur(img) - np.float32(lap.std())) < 1e-4
+    assert orc.calcBlur(synth.adversarial("constant", 16, 16)) == 0.0

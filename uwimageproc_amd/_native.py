@@ -1,0 +1,182 @@
+"""ctypes binding of libuwip.so (the C ABI declared in include/uwip.h).
+
+This is plumbing only: it loads the in-tree shared library built by
+``uwimageproc_amd/csrc/Makefile`` and exposes the C entry points.  There is no
+Python/CPU fallback -- if the library is missing, or no HIP device is present
+when a context is created, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuwip.so")
+
+UWIP_OK = 0
+UWIP_ERR_INVALID = 1
+UWIP_ERR_HIP = 2
+UWIP_ERR_UNSUPPORTED = 3
+UWIP_ERR_NOMEM = 4
+
+
+class UwipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"uwip error {code}: {msg}")
+        self.code = code
+
+
+class BatchU8(C.Structure):
+    """Mirror of ``uwip_batch_u8`` (cv::Mat fields + batch extent)."""
+
+    _fields_ = [
+        ("data", C.c_void_p),
+        ("step", C.c_size_t),
+        ("frame_stride", C.c_size_t),
+        ("rows", C.c_int32),
+        ("cols", C.c_int32),
+        ("channels", C.c_int32),
+        ("frames", C.c_int32),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+
+# name -> (restype, argtypes); every symbol include/uwip.h declares
+_P = C.c_void_p
+_B = C.POINTER(BatchU8)
+SIGNATURES = {
+    "uwip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "uwip_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    "uwip_ctx_destroy": (C.c_int, [_P]),
+    "uwip_last_error": (C.c_char_p, [_P]),
+    "uwip_version": (C.c_char_p, []),
+    "uwip_sync": (C.c_int, [_P]),
+    "uwip_malloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "uwip_free": (C.c_int, [_P, _P]),
+    "uwip_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "uwip_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "uwip_prof_enable": (C.c_int, [_P, C.c_int]),
+    "uwip_prof_reset": (C.c_int, [_P]),
+    "uwip_prof_count": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "uwip_prof_get": (C.c_int, [_P, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "uwip_numChannel": (C.c_int, [C.c_char]),
+    "uwip_numSpace": (C.c_int, [C.c_char]),
+    "uwip_getHistogram": (C.c_int, [_P, _B, _P]),
+    "uwip_stretch_lut": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "uwip_apply_lut": (C.c_int, [_P, _B, _P]),
+    "uwip_imgChannelStretch": (C.c_int, [_P, _B, C.c_int, C.c_int, C.c_int]),
+    "uwip_histretch": (C.c_int, [_P, _B, C.c_char_p, C.c_int, C.c_int]),
+    "uwip_bgr_to_v": (C.c_int, [_P, _B, _B]),
+    "uwip_clahe": (C.c_int, [_P, _B, _B, C.c_double, C.c_int, C.c_int, C.c_int]),
+    "uwip_clahe_per_frame": (C.c_int, [_P, _B, _B, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int]),
+    "uwip_clahe_luts": (C.c_int, [_P, _B, C.c_double, C.c_int, C.c_int, C.c_int, _P]),
+    "uwip_entropy": (C.c_int, [_P, _B, _P]),
+    "uwip_aclahe_sweep": (C.c_int, [_P, _B, C.c_int, _P]),
+}
+
+
+def lib() -> C.CDLL:
+    """Load libuwip.so (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `make -C uwimageproc_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback"
+            )
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)  # AttributeError if the .so is stale
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    lib().uwip_device_count(C.byref(n))
+    return n.value
+
+
+class Context:
+    """Owns a ``uwip_ctx``.  ``stream`` may be a raw hipStream_t handle (int)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._l = lib()
+        h = _P()
+        rc = self._l.uwip_ctx_create(int(device), _P(stream) if stream else None, C.byref(h))
+        if rc != UWIP_OK:
+            raise UwipError(rc, "uwip_ctx_create failed (no HIP device? there is no CPU fallback)")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.uwip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc: int):
+        if rc != UWIP_OK:
+            raise UwipError(rc, self._l.uwip_last_error(self._h).decode("utf-8", "replace"))
+
+    def call(self, name: str, *args):
+        self.check(getattr(self._l, name)(self._h, *args))
+
+    def sync(self):
+        self.call("uwip_sync")
+
+    # ---- profiling ----
+    def prof_enable(self, on: bool = True):
+        self.call("uwip_prof_enable", 1 if on else 0)
+
+    def prof_reset(self):
+        self.call("uwip_prof_reset")
+
+    def prof_results(self) -> dict:
+        n = C.c_int(0)
+        self.call("uwip_prof_count", C.byref(n))
+        out = {}
+        for i in range(n.value):
+            name = C.create_string_buffer(128)
+            ms = C.c_double(0)
+            cnt = C.c_uint64(0)
+            self.call("uwip_prof_get", i, name, 128, C.byref(ms), C.byref(cnt))
+            out[name.value.decode()] = (ms.value, cnt.value)
+        return out
+
+
+def batch_of(t) -> BatchU8:
+    """Describe a torch uint8 CUDA tensor [F,H,W,C], [F,H,W], [H,W,C] or [H,W]
+    (row-major, unit stride on the last axes) as a ``uwip_batch_u8``."""
+    import torch
+
+    assert t.dtype == torch.uint8, "uint8 tensor expected"
+    assert t.is_cuda, "device tensor expected (no CPU path)"
+    shape, st = list(t.shape), list(t.stride())
+    if t.dim() == 2:
+        shape, st = [1] + shape + [1], [0] + st + [1]
+    elif t.dim() == 3:
+        if shape[-1] in (1, 3) and st[-1] == 1 and st[-2] == shape[-1]:
+            shape, st = [1] + shape, [0] + st
+        else:
+            shape, st = shape + [1], st + [1]
+    assert len(shape) == 4
+    F, H, W, Cn = shape
+    assert Cn in (1, 3)
+    if H * W * F > 0:
+        assert st[3] == 1 and st[2] == Cn, "pixels must be packed"
+    b = BatchU8()
+    b.data = t.data_ptr()
+    b.step = st[1] if H > 1 else max(st[1], W * Cn)
+    b.frame_stride = st[0] if F > 1 else max(st[0], b.step * H)
+    b.rows, b.cols, b.channels, b.frames = H, W, Cn, F
+    return b

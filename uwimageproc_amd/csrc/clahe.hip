@@ -1,0 +1,662 @@
+// aclahe hot path for gfx950.
+//
+// cv::CLAHE::apply as driven by modules/aclahe/src/aclahe.cpp:175-187 becomes
+//   k_clahe_tilehist  per-tile 256-bin histograms (per-wave LDS copies,
+//                     BORDER_REFLECT_101 padding folded into the indexing)
+//   k_clahe_lut       clip / redistribute / cumulative LUT, one block per
+//                     (tile, clip limit, frame)
+//   k_clahe_apply     bilinear blend of the 4 neighbouring tile LUTs; a block
+//                     owns a strip of rows that share (ty1, ty2), stages the
+//                     (gx+1) column cells' four LUTs packed as one uint32 per
+//                     grey level in LDS, so each pixel costs one ds_read_b32
+// and the 5 x 51 sweep of aclahe.cpp:160-193 becomes
+//   k_clahe_sweep     a block owns interpolation cells, keeps 17 clip limits'
+//                     packed LUTs and 17 output histograms in LDS, and never
+//                     writes the 255 intermediate images
+//   k_entropy         aclaheEntropy (aclahe.cpp:228-248) on 256-bin counts.
+// All float32 arithmetic keeps OpenCV's operation order (file is compiled with
+// -ffp-contract=off).
+#include "uwip_internal.hpp"
+#include "device_utils.hpp"
+#include <algorithm>
+#include <cmath>
+
+int uwip_launch_hist_internal(uwip_ctx *ctx, const uwip_batch_u8 *img, uint32_t *d_hist);
+
+namespace {
+
+struct ClaheGeom {
+    int rows, cols, gx, gy, tw, th, pc, pr, area;
+    float inv_tw, inv_th, lutScale;
+};
+
+ClaheGeom make_geom(int rows, int cols, int gx, int gy)
+{
+    ClaheGeom g{};
+    g.rows = rows; g.cols = cols; g.gx = gx; g.gy = gy;
+    g.pc = cols; g.pr = rows;
+    if (!(cols % gx == 0 && rows % gy == 0)) {      // both pads, as cv::CLAHE does
+        g.pr = rows + (gy - (rows % gy));
+        g.pc = cols + (gx - (cols % gx));
+    }
+    g.tw = g.pc / gx; g.th = g.pr / gy;
+    g.area = g.tw * g.th;
+    g.inv_tw = 1.0f / (float)g.tw;
+    g.inv_th = 1.0f / (float)g.th;
+    g.lutScale = (float)255 / (float)g.area;
+    return g;
+}
+
+int clip_from_limit(double clipLimit, int area)
+{
+    int clip = 0;
+    if (clipLimit > 0.0) {
+        clip = (int)(clipLimit * area / 256);
+        clip = std::max(clip, 1);
+    }
+    return clip;
+}
+
+// first coordinate p in [0, n] whose cell index floor(p*inv - 0.5f) + 1 is >= c
+// (cell index is non-decreasing in p).  Same float32 expression as the kernels.
+inline int cell_of(int p, float inv) { return (int)floorf((float)p * inv - 0.5f) + 1; }
+
+void cell_starts(int n, int g, float inv, std::vector<int> &starts)
+{
+    starts.assign(g + 2, n);
+    int p = 0;
+    for (int c = 0; c <= g; ++c) {
+        while (p < n && cell_of(p, inv) < c) ++p;
+        starts[c] = p;
+    }
+    starts[g + 1] = n;
+    // cells beyond the last occupied one are empty: starts stay at n
+    for (int c = g; c >= 0; --c) starts[c] = std::min(starts[c], starts[c + 1]);
+}
+
+struct ClipList {
+    int n;
+    int clip[51];
+};
+
+// ---- BGR -> V (max) -------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bgr_to_v(const uint8_t *__restrict__ src, size_t sstep,
+                                                  size_t sfs, uint8_t *__restrict__ dst,
+                                                  size_t dstep, size_t dfs, int rows, int cols,
+                                                  int vec)
+{
+    const int f = blockIdx.z;
+    const int y = blockIdx.y;
+    const uint8_t *s = src + (size_t)f * sfs + (size_t)y * sstep;
+    uint8_t *d = dst + (size_t)f * dfs + (size_t)y * dstep;
+    const int groups = (cols + 15) / 16;
+    for (int g = blockIdx.x * 256 + threadIdx.x; g < groups; g += gridDim.x * 256) {
+        const int x0 = g * 16;
+        if (vec && x0 + 16 <= cols) {
+            const uint4 a = *reinterpret_cast<const uint4 *>(s + (size_t)x0 * 3);
+            const uint4 b = *reinterpret_cast<const uint4 *>(s + (size_t)x0 * 3 + 16);
+            const uint4 c = *reinterpret_cast<const uint4 *>(s + (size_t)x0 * 3 + 32);
+            const uint32_t w[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+            uint32_t o[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int b0 = 3 * i, b1 = 3 * i + 1, b2 = 3 * i + 2;
+                const uint32_t B = (w[b0 >> 2] >> ((b0 & 3) * 8)) & 255u;
+                const uint32_t G = (w[b1 >> 2] >> ((b1 & 3) * 8)) & 255u;
+                const uint32_t R = (w[b2 >> 2] >> ((b2 & 3) * 8)) & 255u;
+                o[i >> 2] |= max(max(B, G), R) << ((i & 3) * 8);
+            }
+            *reinterpret_cast<uint4 *>(d + x0) = make_uint4(o[0], o[1], o[2], o[3]);
+        } else {
+            for (int x = x0; x < min(x0 + 16, cols); ++x) {
+                const uint8_t B = s[3 * x], G = s[3 * x + 1], R = s[3 * x + 2];
+                d[x] = max(max(B, G), R);
+            }
+        }
+    }
+}
+
+// ---- C1a: tile histograms ---------------------------------------------------
+__global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restrict__ src,
+                                                        size_t step, size_t fstride, int rows,
+                                                        int cols, int gx, int tw, int th, int split,
+                                                        int rows_per_part,
+                                                        const int *__restrict__ frame_map,
+                                                        uint32_t *__restrict__ hists, int tiles)
+{
+    __shared__ uint32_t sh[4 * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4 * 256; i += 256) sh[i] = 0;
+    __syncthreads();
+    const int t = blockIdx.x / split, part = blockIdx.x - t * split;
+    const int ty = t / gx, tx = t - ty * gx;
+    const int f = blockIdx.y;
+    const int fr = frame_map ? frame_map[f] : f;
+    const uint8_t *base = src + (size_t)fr * fstride;
+    const int j0 = part * rows_per_part, j1 = min(th, j0 + rows_per_part);
+    uint32_t *my = sh + wave * 256;
+    for (int j = j0 + wave; j < j1; j += 4) {
+        const int y = reflect101(ty * th + j, rows);
+        const uint8_t *row = base + (size_t)y * step;
+        for (int i = lane; i < tw; i += 64) {
+            int x = tx * tw + i;
+            if (x >= cols) x = reflect101(x, cols);
+            atomicAdd(&my[row[x]], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t s = sh[tid] + sh[256 + tid] + sh[512 + tid] + sh[768 + tid];
+    if (s) atomicAdd(&hists[((size_t)f * tiles + t) * 256 + tid], s);
+}
+
+// ---- C1b: clip, redistribute, cumulative LUT --------------------------------
+__global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ hists, int tiles,
+                                                   float lutScale, ClipList cl,
+                                                   const int *__restrict__ frame_clip, int rule,
+                                                   uint8_t *__restrict__ luts)
+{
+    __shared__ uint32_t scratch[8];
+    const int v = threadIdx.x;
+    const int t = blockIdx.x, c = blockIdx.y, f = blockIdx.z;
+    const int ncl = gridDim.y;
+    int h = (int)hists[((size_t)f * tiles + t) * 256 + v];
+    const int clip = frame_clip ? frame_clip[f] : cl.clip[c];
+    if (clip > 0) {
+        const int excess = max(h - clip, 0);
+        h = min(h, clip);
+        const int clipped = (int)block256_sum_u32((uint32_t)excess, scratch);
+        const int batch = clipped / 256;
+        int residual = clipped - batch * 256;
+        h += batch;
+        if (residual != 0) {
+            if (rule == 0) {                                   // OpenCV 3.4.x
+                const int stepr = max(256 / residual, 1);
+                if (v % stepr == 0 && v / stepr < residual) h++;
+            } else {                                           // OpenCV 3.2
+                if (v < residual) h++;
+            }
+        }
+    }
+    const uint32_t sum = block256_incl_scan_u32((uint32_t)h, scratch + 4);
+    luts[(((size_t)f * ncl + c) * tiles + t) * 256 + v] = (uint8_t)sat_u8_rne((float)(int)sum * lutScale);
+}
+
+// ---- C1c: bilinear LUT interpolation, strip per block -------------------------
+// strips[s] = (cy, r0, r1, unused): rows [r0,r1) all have floor(y*inv_th-0.5)+1 == cy.
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__ src, size_t sstep,
+                                                     size_t sfs, uint8_t *__restrict__ dst,
+                                                     size_t dstep, size_t dfs, int cols, int gx,
+                                                     int gy, float inv_tw, float inv_th,
+                                                     const uint8_t *__restrict__ luts,
+                                                     size_t lut_fs, const int4 *__restrict__ strips,
+                                                     const int *__restrict__ frame_map, int TX)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_pack[];   // [(gx+1)][256]
+    const int tid = threadIdx.x;
+    const int4 sd = strips[blockIdx.x];
+    const int cy = sd.x, r0 = sd.y, r1 = sd.z;
+    const int f = blockIdx.y;
+    const int fr = frame_map ? frame_map[f] : f;
+    const uint8_t *L = luts + (size_t)f * lut_fs;
+    const int ty1 = max(cy - 1, 0), ty2 = min(cy, gy - 1);
+    for (int idx = tid; idx < (gx + 1) * 256; idx += 256) {
+        const int cx = idx >> 8, v = idx & 255;
+        const int tx1 = max(cx - 1, 0), tx2 = min(cx, gx - 1);
+        const uint32_t a = L[((size_t)ty1 * gx + tx1) * 256 + v];
+        const uint32_t b = L[((size_t)ty1 * gx + tx2) * 256 + v];
+        const uint32_t c = L[((size_t)ty2 * gx + tx1) * 256 + v];
+        const uint32_t d = L[((size_t)ty2 * gx + tx2) * 256 + v];
+        s_pack[idx] = a | (b << 8) | (c << 16) | (d << 24);
+    }
+    __syncthreads();
+    const uint8_t *sb = src + (size_t)fr * sfs;
+    uint8_t *db = dst + (size_t)fr * dfs;
+    const int tx = tid % TX, ty = tid / TX, TY = 256 / TX;
+    const int groups = (cols + 7) / 8;
+    for (int g = tx; g < groups; g += TX) {
+        const int x0 = g * 8;
+        uint32_t base[8];
+        float xa[8], xa1[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float txf = (float)(x0 + i) * inv_tw - 0.5f;
+            const float fl = floorf(txf);
+            xa[i] = txf - fl;
+            xa1[i] = 1.0f - xa[i];
+            base[i] = (uint32_t)(((int)fl + 1) << 8);
+        }
+        const bool full = VEC && (x0 + 8 <= cols);
+        for (int y = r0 + ty; y < r1; y += TY) {
+            const float tyf = (float)y * inv_th - 0.5f;
+            const float ya = tyf - floorf(tyf), ya1 = 1.0f - ya;
+            const uint8_t *sp = sb + (size_t)y * sstep + x0;
+            uint8_t *dp = db + (size_t)y * dstep + x0;
+            uint32_t w[2];
+            if (full) {
+                const uint2 q = *reinterpret_cast<const uint2 *>(sp);
+                w[0] = q.x; w[1] = q.y;
+            } else {
+                w[0] = w[1] = 0;
+                for (int i = 0; i < min(8, cols - x0); ++i) w[i >> 2] |= (uint32_t)sp[i] << ((i & 3) * 8);
+            }
+            uint32_t o[2] = {0, 0};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const uint32_t v = (w[i >> 2] >> ((i & 3) * 8)) & 255u;
+                const uint32_t p = s_pack[base[i] + v];
+                const float a = (float)(p & 255u), b = (float)((p >> 8) & 255u);
+                const float c = (float)((p >> 16) & 255u), d = (float)(p >> 24);
+                const float res = (a * xa1[i] + b * xa[i]) * ya1 + (c * xa1[i] + d * xa[i]) * ya;
+                o[i >> 2] |= rne_u8_inrange(res) << ((i & 3) * 8);
+            }
+            if (full) {
+                *reinterpret_cast<uint2 *>(dp) = make_uint2(o[0], o[1]);
+            } else {
+                for (int i = 0; i < min(8, cols - x0); ++i) dp[i] = (uint8_t)(o[i >> 2] >> ((i & 3) * 8));
+            }
+        }
+    }
+}
+
+// ---- C3: the sweep, one interpolation cell (chunk) at a time ------------------
+constexpr int SWEEP_NCL = 51;      // clip limits 0, 0.5, ..., 25  (aclahe.cpp:181)
+constexpr int SWEEP_GROUP = 17;    // clip limits per block (51 = 3 x 17)
+
+struct CellItem {
+    int cx, cy;       // cell indices in [0,gx] x [0,gy]
+    int x0, x1;       // pixel columns [x0,x1)
+    int r0, r1;       // pixel rows    [r0,r1)
+    int pad0, pad1;
+};
+
+__global__ __launch_bounds__(256) void k_clahe_sweep(const uint8_t *__restrict__ src, size_t step,
+                                                     size_t fstride, int gx, int gy, float inv_tw,
+                                                     float inv_th,
+                                                     const uint8_t *__restrict__ luts /*[F][51][tiles][256]*/,
+                                                     const CellItem *__restrict__ items, int nitems,
+                                                     int items_per_block,
+                                                     uint32_t *__restrict__ out_hist /*[F][51][256]*/,
+                                                     size_t out_fs)
+{
+    __shared__ uint32_t s_pack[SWEEP_GROUP * 256];
+    __shared__ uint32_t s_hist[SWEEP_GROUP * 256];
+    const int tid = threadIdx.x;
+    const int cg = blockIdx.y, f = blockIdx.z;
+    const int tiles = gx * gy;
+    for (int i = tid; i < SWEEP_GROUP * 256; i += 256) s_hist[i] = 0;
+    const uint8_t *fb = src + (size_t)f * fstride;
+    const uint8_t *L = luts + ((size_t)f * SWEEP_NCL + (size_t)cg * SWEEP_GROUP) * tiles * 256;
+    const int i0 = blockIdx.x * items_per_block, i1 = min(nitems, i0 + items_per_block);
+    for (int it = i0; it < i1; ++it) {
+        const CellItem ci = items[it];
+        const int tx1 = max(ci.cx - 1, 0), tx2 = min(ci.cx, gx - 1);
+        const int ty1 = max(ci.cy - 1, 0), ty2 = min(ci.cy, gy - 1);
+        __syncthreads();
+        for (int idx = tid; idx < SWEEP_GROUP * 256; idx += 256) {
+            const int c = idx >> 8, v = idx & 255;
+            const uint8_t *Lc = L + (size_t)c * tiles * 256;
+            const uint32_t a = Lc[((size_t)ty1 * gx + tx1) * 256 + v];
+            const uint32_t b = Lc[((size_t)ty1 * gx + tx2) * 256 + v];
+            const uint32_t cc = Lc[((size_t)ty2 * gx + tx1) * 256 + v];
+            const uint32_t d = Lc[((size_t)ty2 * gx + tx2) * 256 + v];
+            s_pack[idx] = a | (b << 8) | (cc << 16) | (d << 24);
+        }
+        __syncthreads();
+        const int w = ci.x1 - ci.x0;
+        const int npix = w * (ci.r1 - ci.r0);
+        const float inv_w = 1.0f / (float)w;
+        for (int p = tid; p < npix; p += 256) {
+            int q = (int)(((float)p + 0.5f) * inv_w);
+            int r = p - q * w;
+            if (r < 0) { q--; r += w; }
+            if (r >= w) { q++; r -= w; }
+            const int x = ci.x0 + r, y = ci.r0 + q;
+            const float txf = (float)x * inv_tw - 0.5f;
+            const float xa = txf - floorf(txf), xa1 = 1.0f - xa;
+            const float tyf = (float)y * inv_th - 0.5f;
+            const float ya = tyf - floorf(tyf), ya1 = 1.0f - ya;
+            const uint32_t v = fb[(size_t)y * step + x];
+#pragma unroll
+            for (int c = 0; c < SWEEP_GROUP; ++c) {
+                const uint32_t pk = s_pack[c * 256 + v];
+                const float a = (float)(pk & 255u), b = (float)((pk >> 8) & 255u);
+                const float cc = (float)((pk >> 16) & 255u), d = (float)(pk >> 24);
+                const float res = (a * xa1 + b * xa) * ya1 + (cc * xa1 + d * xa) * ya;
+                atomicAdd(&s_hist[c * 256 + rne_u8_inrange(res)], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *out = out_hist + (size_t)f * out_fs + (size_t)cg * SWEEP_GROUP * 256;
+    for (int i = tid; i < SWEEP_GROUP * 256; i += 256) {
+        const uint32_t s = s_hist[i];
+        if (s) atomicAdd(&out[i], s);
+    }
+}
+
+// ---- C2: entropy of 256-bin counts ---------------------------------------------
+__global__ __launch_bounds__(256) void k_entropy(const uint32_t *__restrict__ hist, int rows,
+                                                 int cols, float *__restrict__ out)
+{
+    __shared__ double s_term[256];
+    const int v = threadIdx.x;
+    const size_t h = blockIdx.x;
+    const float p = (float)hist[h * 256 + v] / (float)(cols * rows);
+    s_term[v] = (double)p * log2((double)p + 0.00001);
+    __syncthreads();
+    if (v == 0) {
+        float e = 0.0f;
+        for (int i = 0; i < 256; ++i) e = (float)((double)e + s_term[i]);
+        out[h] = -e;
+    }
+}
+
+// -----------------------------------------------------------------------------
+bool aligned_for(const uwip_batch_u8 *b, size_t a)
+{
+    return ((uintptr_t)b->data % a == 0) && (b->step % a == 0) && (b->frames <= 1 || b->frame_stride % a == 0);
+}
+
+int launch_tilehist(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g, const int *d_frame_map,
+                    int nf, uint32_t *d_hists)
+{
+    const int tiles = g.gx * g.gy;
+    UWIP_HIP(ctx, hipMemsetAsync(d_hists, 0, sizeof(uint32_t) * 256 * (size_t)tiles * nf, ctx->stream));
+    int split = (int)((4096 + (size_t)tiles * nf - 1) / ((size_t)tiles * nf));
+    split = std::max(1, std::min(split, std::max(1, g.th / 8)));
+    const int rpp = (g.th + split - 1) / split;
+    dim3 grid((unsigned)(tiles * split), (unsigned)nf);
+    uwip_kscope ks(ctx, "k_clahe_tilehist");
+    k_clahe_tilehist<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
+                                                    g.rows, g.cols, g.gx, g.tw, g.th, split, rpp,
+                                                    d_frame_map, d_hists, tiles);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}
+
+int launch_lut(uwip_ctx *ctx, const ClaheGeom &g, const uint32_t *d_hists, const ClipList &cl,
+               const int *d_frame_clip, int nf, int rule, uint8_t *d_luts)
+{
+    const int tiles = g.gx * g.gy;
+    dim3 grid((unsigned)tiles, (unsigned)cl.n, (unsigned)nf);
+    uwip_kscope ks(ctx, "k_clahe_lut");
+    k_clahe_lut<<<grid, 256, 0, ctx->stream>>>(d_hists, tiles, g.lutScale, cl, d_frame_clip, rule, d_luts);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}
+
+// strip table for (rows, gy, th, max_rows): built once per geometry and cached
+int build_strips(uwip_ctx *ctx, const ClaheGeom &g, int max_rows, const int4 **d_strips, int *nstrips)
+{
+    char key[96];
+    snprintf(key, sizeof key, "strips:%d:%d:%d:%d", g.rows, g.gy, g.th, max_rows);
+    size_t bytes = 0;
+    const void *d = uwip_table_find(ctx, key, &bytes);
+    if (!d) {
+        std::vector<int> ys;
+        cell_starts(g.rows, g.gy, g.inv_th, ys);
+        std::vector<int4> strips;
+        for (int cy = 0; cy <= g.gy; ++cy)
+            for (int r = ys[cy]; r < ys[cy + 1]; r += max_rows)
+                strips.push_back(make_int4(cy, r, std::min(r + max_rows, ys[cy + 1]), 0));
+        bytes = strips.size() * sizeof(int4);
+        d = uwip_table_put(ctx, key, strips.data(), bytes);
+        if (!d) return UWIP_ERR_NOMEM;
+    }
+    *d_strips = (const int4 *)d;
+    *nstrips = (int)(bytes / sizeof(int4));
+    return UWIP_OK;
+}
+
+int launch_apply(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, const ClaheGeom &g,
+                 const uint8_t *d_luts, size_t lut_fs, const int *d_frame_map, int nf)
+{
+    const int4 *d_strips = nullptr;
+    int nstrips = 0;
+    const int max_rows = g.gx >= 16 ? 16 : 8;
+    int rc = build_strips(ctx, g, max_rows, &d_strips, &nstrips);
+    if (rc) return rc;
+    if (nstrips == 0) return UWIP_OK;
+    const int groups = (g.cols + 7) / 8;
+    int TX = 256;
+    while (TX > 32 && TX / 2 >= groups) TX /= 2;
+    const size_t lds = (size_t)(g.gx + 1) * 256 * sizeof(uint32_t);
+    const bool vec = aligned_for(src, 8) && aligned_for(dst, 8);
+    dim3 grid((unsigned)nstrips, (unsigned)nf);
+    uwip_kscope ks(ctx, "k_clahe_apply");
+    if (vec)
+        k_clahe_apply<true><<<grid, 256, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
+                                                             (uint8_t *)dst->data, dst->step, dst->frame_stride, g.cols,
+                                                             g.gx, g.gy, g.inv_tw, g.inv_th, d_luts, lut_fs, d_strips,
+                                                             d_frame_map, TX);
+    else
+        k_clahe_apply<false><<<grid, 256, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
+                                                              (uint8_t *)dst->data, dst->step, dst->frame_stride, g.cols,
+                                                              g.gx, g.gy, g.inv_tw, g.inv_th, d_luts, lut_fs, d_strips,
+                                                              d_frame_map, TX);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}
+
+int check_pair(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst)
+{
+    int rc = uwip_check_batch(ctx, src, 1);
+    if (rc) return rc;
+    rc = uwip_check_batch(ctx, dst, 1);
+    if (rc) return rc;
+    UWIP_REQUIRE(ctx, src->rows == dst->rows && src->cols == dst->cols && src->frames == dst->frames,
+                 "src/dst shape mismatch");
+    return UWIP_OK;
+}
+
+int check_grid(uwip_ctx *ctx, int gx, int gy)
+{
+    UWIP_REQUIRE(ctx, gx >= 1 && gy >= 1 && gx <= 128 && gy <= 128, "tile grid must be in [1,128]");
+    return UWIP_OK;
+}
+
+}  // namespace
+
+// ---- exported entry points --------------------------------------------------
+
+UWIP_API int uwip_bgr_to_v(uwip_ctx *ctx, const uwip_batch_u8 *bgr, const uwip_batch_u8 *v)
+{
+    int rc = uwip_check_batch(ctx, bgr, 3);
+    if (rc) return rc;
+    rc = uwip_check_batch(ctx, v, 1);
+    if (rc) return rc;
+    UWIP_REQUIRE(ctx, bgr->rows == v->rows && bgr->cols == v->cols && bgr->frames == v->frames, "shape mismatch");
+    if (uwip_batch_empty(bgr)) return UWIP_OK;
+    const int groups = (bgr->cols + 15) / 16;
+    dim3 grid(uwip_cdiv(groups, 256), (unsigned)bgr->rows, (unsigned)bgr->frames);
+    UWIP_REQUIRE(ctx, bgr->rows <= 65535 && bgr->frames <= 65535, "too many rows/frames for one launch");
+    const int vec = aligned_for(bgr, 16) && aligned_for(v, 16);
+    uwip_kscope ks(ctx, "k_bgr_to_v");
+    k_bgr_to_v<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)bgr->data, bgr->step, bgr->frame_stride,
+                                              (uint8_t *)v->data, v->step, v->frame_stride, bgr->rows, bgr->cols, vec);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_clahe_luts(uwip_ctx *ctx, const uwip_batch_u8 *src, double clipLimit, int gx, int gy,
+                             int residual_rule, uint8_t *d_luts)
+{
+    int rc = uwip_check_batch(ctx, src, 1);
+    if (rc) return rc;
+    rc = check_grid(ctx, gx, gy);
+    if (rc) return rc;
+    if (uwip_batch_empty(src)) return UWIP_OK;
+    UWIP_REQUIRE(ctx, d_luts != nullptr, "null LUT buffer");
+    const ClaheGeom g = make_geom(src->rows, src->cols, gx, gy);
+    const int tiles = gx * gy;
+    uint32_t *d_hists = (uint32_t *)uwip_ws(ctx, "clahe.tilehist", sizeof(uint32_t) * 256 * (size_t)tiles * src->frames);
+    if (!d_hists) return UWIP_ERR_NOMEM;
+    rc = launch_tilehist(ctx, src, g, nullptr, src->frames, d_hists);
+    if (rc) return rc;
+    ClipList cl{};
+    cl.n = 1;
+    cl.clip[0] = clip_from_limit(clipLimit, g.area);
+    return launch_lut(ctx, g, d_hists, cl, nullptr, src->frames, residual_rule, d_luts);
+}
+
+UWIP_API int uwip_clahe(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, double clipLimit,
+                        int gx, int gy, int residual_rule)
+{
+    int rc = check_pair(ctx, src, dst);
+    if (rc) return rc;
+    rc = check_grid(ctx, gx, gy);
+    if (rc) return rc;
+    if (uwip_batch_empty(src)) return UWIP_OK;
+    const ClaheGeom g = make_geom(src->rows, src->cols, gx, gy);
+    const int tiles = gx * gy;
+    uint8_t *d_luts = (uint8_t *)uwip_ws(ctx, "clahe.luts", (size_t)256 * tiles * src->frames);
+    if (!d_luts) return UWIP_ERR_NOMEM;
+    rc = uwip_clahe_luts(ctx, src, clipLimit, gx, gy, residual_rule, d_luts);
+    if (rc) return rc;
+    return launch_apply(ctx, src, dst, g, d_luts, (size_t)tiles * 256, nullptr, src->frames);
+}
+
+UWIP_API int uwip_clahe_per_frame(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst,
+                                  const double *h_clipLimit, const int32_t *h_grid, int residual_rule)
+{
+    int rc = check_pair(ctx, src, dst);
+    if (rc) return rc;
+    if (uwip_batch_empty(src)) return UWIP_OK;
+    UWIP_REQUIRE(ctx, h_clipLimit && h_grid, "null parameter arrays");
+    const int F = src->frames;
+    for (int f = 0; f < F; ++f) {
+        rc = check_grid(ctx, h_grid[f], h_grid[f]);
+        if (rc) return rc;
+    }
+    // group frames by grid size; one (tilehist, lut, apply) triple per group
+    std::vector<int> order(F);
+    for (int f = 0; f < F; ++f) order[f] = f;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h_grid[a] < h_grid[b]; });
+    int *h_map = (int *)uwip_host_ws(ctx, "clahe.pf.map", sizeof(int) * 2 * (size_t)F);
+    int *d_map = (int *)uwip_ws(ctx, "clahe.pf.map", sizeof(int) * 2 * (size_t)F);
+    if (!h_map || !d_map) return UWIP_ERR_NOMEM;
+    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int *h_clip = h_map + F, *d_clip = d_map + F;
+    for (int i = 0; i < F; ++i) {
+        const int f = order[i];
+        h_map[i] = f;
+        const ClaheGeom g = make_geom(src->rows, src->cols, h_grid[f], h_grid[f]);
+        h_clip[i] = clip_from_limit(h_clipLimit[f], g.area);
+    }
+    UWIP_HIP(ctx, hipMemcpyAsync(d_map, h_map, sizeof(int) * 2 * (size_t)F, hipMemcpyHostToDevice, ctx->stream));
+    size_t max_tiles = 0;
+    for (int f = 0; f < F; ++f) max_tiles = std::max(max_tiles, (size_t)h_grid[f] * h_grid[f]);
+    uint32_t *d_hists = (uint32_t *)uwip_ws(ctx, "clahe.tilehist", sizeof(uint32_t) * 256 * max_tiles * F);
+    uint8_t *d_luts = (uint8_t *)uwip_ws(ctx, "clahe.luts", (size_t)256 * max_tiles * F);
+    if (!d_hists || !d_luts) return UWIP_ERR_NOMEM;
+    int i = 0;
+    while (i < F) {
+        int j = i;
+        const int gsz = h_grid[order[i]];
+        while (j < F && h_grid[order[j]] == gsz) ++j;
+        const int nf = j - i;
+        const ClaheGeom g = make_geom(src->rows, src->cols, gsz, gsz);
+        const int tiles = gsz * gsz;
+        rc = launch_tilehist(ctx, src, g, d_map + i, nf, d_hists);
+        if (rc) return rc;
+        ClipList cl{};
+        cl.n = 1;
+        rc = launch_lut(ctx, g, d_hists, cl, d_clip + i, nf, residual_rule, d_luts);
+        if (rc) return rc;
+        // d_hists / d_luts are reused by the next group: stream order keeps that safe
+        rc = launch_apply(ctx, src, dst, g, d_luts, (size_t)tiles * 256, d_map + i, nf);
+        if (rc) return rc;
+        i = j;
+    }
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_entropy(uwip_ctx *ctx, const uwip_batch_u8 *src, float *d_entropy)
+{
+    int rc = uwip_check_batch(ctx, src, 1);
+    if (rc) return rc;
+    if (src->frames == 0) return UWIP_OK;
+    UWIP_REQUIRE(ctx, d_entropy != nullptr, "null output");
+    UWIP_REQUIRE(ctx, !uwip_batch_empty(src), "entropy of an empty image");
+    uint32_t *d_hist = (uint32_t *)uwip_ws(ctx, "entropy.hist", sizeof(uint32_t) * 256 * (size_t)src->frames);
+    if (!d_hist) return UWIP_ERR_NOMEM;
+    rc = uwip_launch_hist_internal(ctx, src, d_hist);
+    if (rc) return rc;
+    uwip_kscope ks(ctx, "k_entropy");
+    k_entropy<<<src->frames, 256, 0, ctx->stream>>>(d_hist, src->rows, src->cols, d_entropy);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int residual_rule, float *d_entropy)
+{
+    static const int BlockSize[5] = {2, 4, 8, 16, 32};          // aclahe.cpp:161
+    int rc = uwip_check_batch(ctx, src, 1);
+    if (rc) return rc;
+    if (src->frames == 0) return UWIP_OK;
+    UWIP_REQUIRE(ctx, d_entropy != nullptr, "null output");
+    UWIP_REQUIRE(ctx, !uwip_batch_empty(src), "sweep of an empty image");
+    UWIP_REQUIRE(ctx, src->frames <= 65535, "too many frames for one launch");
+    const int F = src->frames;
+    const size_t out_fs = (size_t)5 * SWEEP_NCL * 256;
+    uint32_t *d_out = (uint32_t *)uwip_ws(ctx, "sweep.outhist", sizeof(uint32_t) * out_fs * F);
+    uint32_t *d_hists = (uint32_t *)uwip_ws(ctx, "clahe.tilehist", sizeof(uint32_t) * 256 * (size_t)1024 * F);
+    uint8_t *d_luts = (uint8_t *)uwip_ws(ctx, "sweep.luts", (size_t)256 * 1024 * SWEEP_NCL * F);
+    if (!d_out || !d_hists || !d_luts) return UWIP_ERR_NOMEM;
+    UWIP_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(uint32_t) * out_fs * F, ctx->stream));
+    for (int gi = 0; gi < 5; ++gi) {
+        const int gsz = BlockSize[gi];
+        const ClaheGeom g = make_geom(src->rows, src->cols, gsz, gsz);
+        rc = launch_tilehist(ctx, src, g, nullptr, F, d_hists);
+        if (rc) return rc;
+        ClipList cl{};
+        cl.n = 0;
+        for (float c = 0.0f; c <= 25.0f; c += 0.5f) cl.clip[cl.n++] = clip_from_limit((double)c, g.area);
+        rc = launch_lut(ctx, g, d_hists, cl, nullptr, F, residual_rule, d_luts);
+        if (rc) return rc;
+        // work items: interpolation cells cut into row chunks of <= ~16K pixels (cached per geometry)
+        char key[96];
+        snprintf(key, sizeof key, "cells:%d:%d:%d", g.rows, g.cols, gsz);
+        size_t bytes = 0;
+        const void *d_tab = uwip_table_find(ctx, key, &bytes);
+        if (!d_tab) {
+            std::vector<int> xs, ys;
+            cell_starts(g.cols, g.gx, g.inv_tw, xs);
+            cell_starts(g.rows, g.gy, g.inv_th, ys);
+            std::vector<CellItem> items;
+            for (int cy = 0; cy <= g.gy; ++cy) {
+                for (int cx = 0; cx <= g.gx; ++cx) {
+                    const int w = xs[cx + 1] - xs[cx], h = ys[cy + 1] - ys[cy];
+                    if (w <= 0 || h <= 0) continue;
+                    const int rows_per = std::max(1, 16384 / w);
+                    for (int r = ys[cy]; r < ys[cy + 1]; r += rows_per) {
+                        CellItem ci{};
+                        ci.cx = cx; ci.cy = cy; ci.x0 = xs[cx]; ci.x1 = xs[cx + 1];
+                        ci.r0 = r; ci.r1 = std::min(r + rows_per, ys[cy + 1]);
+                        items.push_back(ci);
+                    }
+                }
+            }
+            bytes = items.size() * sizeof(CellItem);
+            d_tab = uwip_table_put(ctx, key, items.data(), bytes);
+            if (!d_tab) return UWIP_ERR_NOMEM;
+        }
+        const CellItem *d_items = (const CellItem *)d_tab;
+        const int nitems = (int)(bytes / sizeof(CellItem));
+        const int cell_px = std::max(1, g.tw * g.th);
+        const int ipb = std::max(1, std::min(16, 16384 / cell_px));
+        dim3 grid(uwip_cdiv(nitems, ipb), SWEEP_NCL / SWEEP_GROUP, (unsigned)F);
+        uwip_kscope ks(ctx, "k_clahe_sweep");
+        k_clahe_sweep<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.gx,
+                                                     g.gy, g.inv_tw, g.inv_th, d_luts, d_items, nitems, ipb,
+                                                     d_out + (size_t)gi * SWEEP_NCL * 256, out_fs);
+        UWIP_HIP(ctx, hipGetLastError());
+    }
+    {
+        uwip_kscope ks(ctx, "k_entropy");
+        k_entropy<<<F * 5 * SWEEP_NCL, 256, 0, ctx->stream>>>(d_out, src->rows, src->cols, d_entropy);
+        UWIP_HIP(ctx, hipGetLastError());
+    }
+    return UWIP_OK;
+}

@@ -1,0 +1,263 @@
+// Context, device memory and per-kernel event profiling for libuwip.so.
+#include "uwip_internal.hpp"
+#include <cstring>
+
+UWIP_API const char *uwip_version(void) { return "uwip-mi355x 0.1 (gfx950)"; }
+
+UWIP_API int uwip_device_count(int *count)
+{
+    if (!count) return UWIP_ERR_INVALID;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return UWIP_ERR_HIP; }
+    *count = n;
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_ctx_create(int device, void *stream, uwip_ctx **out)
+{
+    if (!out) return UWIP_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return UWIP_ERR_HIP;  // no CPU fallback
+    if (device < 0 || device >= n) return UWIP_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return UWIP_ERR_HIP;
+    uwip_ctx *ctx = new (std::nothrow) uwip_ctx();
+    if (!ctx) return UWIP_ERR_NOMEM;
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+        ctx->own_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return UWIP_ERR_HIP;
+        }
+        ctx->own_stream = true;
+    }
+    *out = ctx;
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_ctx_destroy(uwip_ctx *ctx)
+{
+    if (!ctx) return UWIP_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &p : ctx->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto &kv : ctx->ws) if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    for (auto &kv : ctx->hs) if (kv.second.ptr) (void)hipHostFree(kv.second.ptr);
+    for (auto &kv : ctx->tables) if (kv.second.ptr) (void)hipFree(kv.second.ptr);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return UWIP_OK;
+}
+
+UWIP_API const char *uwip_last_error(const uwip_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+UWIP_API int uwip_sync(uwip_ctx *ctx)
+{
+    if (!ctx) return UWIP_ERR_INVALID;
+    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_malloc(uwip_ctx *ctx, size_t bytes, void **d_ptr)
+{
+    if (!ctx || !d_ptr) return UWIP_ERR_INVALID;
+    *d_ptr = nullptr;
+    if (bytes == 0) return UWIP_OK;
+    UWIP_HIP(ctx, hipSetDevice(ctx->device));
+    UWIP_HIP(ctx, hipMalloc(d_ptr, bytes));
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_free(uwip_ctx *ctx, void *d_ptr)
+{
+    if (!ctx) return UWIP_ERR_INVALID;
+    if (!d_ptr) return UWIP_OK;
+    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    UWIP_HIP(ctx, hipFree(d_ptr));
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_memcpy_h2d(uwip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    if (!ctx) return UWIP_ERR_INVALID;
+    if (bytes == 0) return UWIP_OK;
+    UWIP_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_memcpy_d2h(uwip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    if (!ctx) return UWIP_ERR_INVALID;
+    if (bytes == 0) return UWIP_OK;
+    UWIP_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return UWIP_OK;
+}
+
+void *uwip_ws(uwip_ctx *ctx, const char *name, size_t bytes)
+{
+    uwip_ws_buf &b = ctx->ws[name];
+    if (b.bytes >= bytes && b.ptr) return b.ptr;
+    if (b.ptr) {
+        // grow: the old buffer may still be in use by queued kernels
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipFree(b.ptr);
+        b.ptr = nullptr; b.bytes = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&b.ptr, want);
+    if (e != hipSuccess) {
+        b.ptr = nullptr;
+        ctx->fail(UWIP_ERR_NOMEM, "workspace hipMalloc", hipGetErrorString(e));
+        return nullptr;
+    }
+    b.bytes = want;
+    return b.ptr;
+}
+
+void *uwip_host_ws(uwip_ctx *ctx, const char *name, size_t bytes)
+{
+    uwip_ws_buf &b = ctx->hs[name];
+    if (b.bytes >= bytes && b.ptr) return b.ptr;
+    if (b.ptr) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipHostFree(b.ptr);
+        b.ptr = nullptr; b.bytes = 0;
+    }
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipHostMalloc(&b.ptr, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        b.ptr = nullptr;
+        ctx->fail(UWIP_ERR_NOMEM, "pinned hipHostMalloc", hipGetErrorString(e));
+        return nullptr;
+    }
+    b.bytes = want;
+    return b.ptr;
+}
+
+const void *uwip_table_find(uwip_ctx *ctx, const std::string &key, size_t *bytes)
+{
+    auto it = ctx->tables.find(key);
+    if (it == ctx->tables.end()) return nullptr;
+    if (bytes) *bytes = it->second.bytes;
+    return it->second.ptr;
+}
+
+const void *uwip_table_put(uwip_ctx *ctx, const std::string &key, const void *host, size_t bytes)
+{
+    uwip_ws_buf b;
+    if (hipMalloc(&b.ptr, bytes ? bytes : 16) != hipSuccess) {
+        ctx->fail(UWIP_ERR_NOMEM, "table hipMalloc");
+        return nullptr;
+    }
+    b.bytes = bytes;
+    if (bytes && hipMemcpy(b.ptr, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(b.ptr);
+        ctx->fail(UWIP_ERR_HIP, "table upload");
+        return nullptr;
+    }
+    ctx->tables[key] = b;
+    return b.ptr;
+}
+
+// ---- profiling ---------------------------------------------------------
+
+static hipEvent_t take_event(uwip_ctx *ctx)
+{
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+uwip_kscope::uwip_kscope(uwip_ctx *c, const char *name) : ctx(c)
+{
+    if (!ctx || !ctx->prof) return;
+    auto it = ctx->prof_index.find(name);
+    if (it == ctx->prof_index.end()) {
+        rec = (int)ctx->prof_recs.size();
+        ctx->prof_recs.push_back(uwip_prof_rec{name, 0.0, 0});
+        ctx->prof_index[name] = rec;
+    } else {
+        rec = it->second;
+    }
+    a = take_event(ctx);
+    b = take_event(ctx);
+    if (!a || !b) { rec = -1; return; }
+    (void)hipEventRecord(a, ctx->stream);
+}
+
+uwip_kscope::~uwip_kscope()
+{
+    if (rec < 0) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->prof_pending.push_back({rec, a, b});
+    if (ctx->prof_pending.size() > 4096) (void)uwip_prof_flush(ctx);
+}
+
+int uwip_prof_flush(uwip_ctx *ctx)
+{
+    if (ctx->prof_pending.empty()) return UWIP_OK;
+    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto &p : ctx->prof_pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            ctx->prof_recs[p.rec].total_ms += ms;
+            ctx->prof_recs[p.rec].launches += 1;
+        }
+        ctx->event_pool.push_back(p.a);
+        ctx->event_pool.push_back(p.b);
+    }
+    ctx->prof_pending.clear();
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_prof_enable(uwip_ctx *ctx, int on)
+{
+    if (!ctx) return UWIP_ERR_INVALID;
+    int rc = uwip_prof_flush(ctx);
+    ctx->prof = on != 0;
+    return rc;
+}
+
+UWIP_API int uwip_prof_reset(uwip_ctx *ctx)
+{
+    if (!ctx) return UWIP_ERR_INVALID;
+    int rc = uwip_prof_flush(ctx);
+    ctx->prof_recs.clear();
+    ctx->prof_index.clear();
+    return rc;
+}
+
+UWIP_API int uwip_prof_count(uwip_ctx *ctx, int *n)
+{
+    if (!ctx || !n) return UWIP_ERR_INVALID;
+    int rc = uwip_prof_flush(ctx);
+    *n = (int)ctx->prof_recs.size();
+    return rc;
+}
+
+UWIP_API int uwip_prof_get(uwip_ctx *ctx, int index, char *name, size_t name_cap,
+                           double *total_ms, uint64_t *launches)
+{
+    if (!ctx) return UWIP_ERR_INVALID;
+    if (index < 0 || index >= (int)ctx->prof_recs.size()) return ctx->fail(UWIP_ERR_INVALID, "prof index out of range");
+    const uwip_prof_rec &r = ctx->prof_recs[index];
+    if (name && name_cap) {
+        std::strncpy(name, r.name.c_str(), name_cap - 1);
+        name[name_cap - 1] = 0;
+    }
+    if (total_ms) *total_ms = r.total_ms;
+    if (launches) *launches = r.launches;
+    return UWIP_OK;
+}

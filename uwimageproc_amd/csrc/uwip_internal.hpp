@@ -1,0 +1,98 @@
+// Internal definitions shared by the HIP translation units of libuwip.so.
+// gfx950 (MI355X) only: wave = 64 lanes, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/uwip.h"
+
+#define UWIP_API extern "C" __attribute__((visibility("default")))
+
+struct uwip_prof_rec {
+    std::string name;
+    double total_ms = 0.0;
+    uint64_t launches = 0;
+};
+
+struct uwip_ws_buf {
+    void *ptr = nullptr;
+    size_t bytes = 0;
+};
+
+struct uwip_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // named, grow-only device workspaces: no hipMalloc in steady state
+    std::map<std::string, uwip_ws_buf> ws;
+    // named pinned host staging buffers
+    std::map<std::string, uwip_ws_buf> hs;
+    // immutable device tables keyed by their geometry (strip / cell lists)
+    std::map<std::string, uwip_ws_buf> tables;
+    // profiling
+    bool prof = false;
+    std::vector<uwip_prof_rec> prof_recs;
+    std::map<std::string, int> prof_index;
+    struct pending_t { int rec; hipEvent_t a, b; };
+    std::vector<pending_t> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+
+    int fail(int code, const char *what, const char *detail = nullptr)
+    {
+        err = what;
+        if (detail) { err += ": "; err += detail; }
+        return code;
+    }
+};
+
+void *uwip_ws(uwip_ctx *ctx, const char *name, size_t bytes);       // nullptr on failure (ctx->err set)
+void *uwip_host_ws(uwip_ctx *ctx, const char *name, size_t bytes);  // pinned host
+// Cached immutable device table: uploaded once (blocking) the first time `key` is seen.
+const void *uwip_table_find(uwip_ctx *ctx, const std::string &key, size_t *bytes);
+const void *uwip_table_put(uwip_ctx *ctx, const std::string &key, const void *host, size_t bytes);
+int uwip_prof_flush(uwip_ctx *ctx);
+
+#define UWIP_HIP(ctx, expr)                                                          \
+    do {                                                                             \
+        hipError_t e__ = (expr);                                                     \
+        if (e__ != hipSuccess) return (ctx)->fail(UWIP_ERR_HIP, #expr, hipGetErrorString(e__)); \
+    } while (0)
+
+#define UWIP_REQUIRE(ctx, cond, msg)                                   \
+    do {                                                               \
+        if (!(cond)) return (ctx)->fail(UWIP_ERR_INVALID, msg, #cond); \
+    } while (0)
+
+// RAII launch bracket: when profiling is on, records events around a kernel.
+struct uwip_kscope {
+    uwip_ctx *ctx;
+    int rec = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    uwip_kscope(uwip_ctx *c, const char *name);
+    ~uwip_kscope();
+};
+
+static inline int uwip_check_batch(uwip_ctx *ctx, const uwip_batch_u8 *b, int channels /*0=any*/)
+{
+    if (!ctx) return UWIP_ERR_INVALID;
+    UWIP_REQUIRE(ctx, b != nullptr, "null batch");
+    UWIP_REQUIRE(ctx, b->rows >= 0 && b->cols >= 0 && b->frames >= 0, "negative extent");
+    UWIP_REQUIRE(ctx, b->channels == 1 || b->channels == 3, "channels must be 1 or 3");
+    if (channels) UWIP_REQUIRE(ctx, b->channels == channels, "wrong channel count");
+    UWIP_REQUIRE(ctx, b->step >= (size_t)b->cols * b->channels, "step smaller than a row");
+    if (b->frames > 1) UWIP_REQUIRE(ctx, b->frame_stride >= b->step * (size_t)b->rows, "frame_stride smaller than a frame");
+    if ((size_t)b->rows * b->cols * b->frames > 0) UWIP_REQUIRE(ctx, b->data != nullptr, "null data");
+    UWIP_REQUIRE(ctx, (uint64_t)b->rows * (uint64_t)b->cols < (1ull << 31), "frame too large");
+    return UWIP_OK;
+}
+
+static inline bool uwip_batch_empty(const uwip_batch_u8 *b)
+{
+    return (size_t)b->rows * b->cols * b->frames == 0;
+}
+
+static inline unsigned uwip_cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
