@@ -59,6 +59,7 @@ def test_histretch_strided_rows_and_unaligned(ctx, orc):
     step = cols * 3 + 13
     buf = torch.zeros(rows * step + 32, dtype=torch.uint8, device="cuda")
     for off in (0, 1, 16):
+        buf.zero_()
         view = buf[off:off + rows * step].view(rows, step)[:, :cols * 3].view(rows, cols, 3)
         view.copy_(_dev(img))
         b = batch_of(view)

@@ -172,11 +172,16 @@ def batch_of(t) -> BatchU8:
     assert len(shape) == 4
     F, H, W, Cn = shape
     assert Cn in (1, 3)
+    # strides of size-1 axes carry no information
+    if Cn == 1:
+        st[3] = 1
+    if W == 1:
+        st[2] = Cn
     if H * W * F > 0:
         assert st[3] == 1 and st[2] == Cn, "pixels must be packed"
     b = BatchU8()
     b.data = t.data_ptr()
-    b.step = st[1] if H > 1 else max(st[1], W * Cn)
-    b.frame_stride = st[0] if F > 1 else max(st[0], b.step * H)
+    b.step = st[1] if H > 1 else W * Cn
+    b.frame_stride = st[0] if F > 1 else b.step * H
     b.rows, b.cols, b.channels, b.frames = H, W, Cn, F
     return b
