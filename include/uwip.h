@@ -141,6 +141,44 @@ int uwip_entropy(uwip_ctx *ctx, const uwip_batch_u8 *src, float *d_entropy);
 int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int residual_rule,
                       float *d_entropy);
 
+/* ---- bgdehaze (D1-D6) ---------------------------------------------------- */
+/* All real-valued results are float64, as in the reference.  The input is the
+ * uint8 BGR frame cv2.imread returns; normI = (I - min)/(max - min)
+ * (modules/bgdehaze/main.py:17) is formed inside. */
+
+/* Background_light(normI, w), BGDehaze.py:14-26.  d_B: [frames][3] (BGR);
+ * d_idx (may be NULL): [frames][2] row-major pixel indices of the two minima.
+ * Ties take the first index (the reference's order is unspecified, B-9). */
+int uwip_dehaze_background_light(uwip_ctx *ctx, const uwip_batch_u8 *in, int w, double *d_B,
+                                 int32_t *d_idx);
+
+/* transmission_map(normI, 15) with B injected, BGDehaze.py:28-37.
+ * d_B: [frames][3]; d_t: [frames][2][rows][cols] (blue, green), before the
+ * 0.2 clamp. */
+int uwip_dehaze_transmission(uwip_ctx *ctx, const uwip_batch_u8 *in, const double *d_B, double *d_t);
+
+/* guided_filter(I, p, r, eps), guidedfilter.py:54-103, for the guide form both
+ * call sites use: an 8-bit 3-channel image normalised by its global min/max.
+ * d_p, d_q: [frames][rows][cols].  Needs rows, cols >= 2r+1. */
+int uwip_guided_filter(uwip_ctx *ctx, const uwip_batch_u8 *guide, const double *d_p, int r, double eps,
+                       double *d_q);
+
+/* generate_results(), modules/bgdehaze/main.py:14-20: uint8 BGR in -> uint8
+ * BGR out.  flags: UWIP_DEHAZE_FULL runs adaptiveExp_map (BGDehaze.py:71-89),
+ * without it the chain stops after RC_correction (:59-69).  As written, a 0/0
+ * in the exposure map S (:83) turns the whole frame into NaN -> black
+ * (SURVEY.md B-11); that is reproduced unless UWIP_DEHAZE_GUARD_S is set, which
+ * substitutes S = 1 there (a documented deviation).
+ * `out` may be NULL when only taps are wanted.
+ * Optional taps / injection (device pointers, may be NULL):
+ *   d_B_inject   [frames][3]              use this background light (parity tests)
+ *   d_refined_t  [frames][2][rows][cols]  refined_t (:39-48)
+ *   d_float_out  [frames][rows][cols][3]  the float64 image before *255 */
+#define UWIP_DEHAZE_FULL     1
+#define UWIP_DEHAZE_GUARD_S  2
+int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batch_u8 *out, int w, int flags,
+                const double *d_B_inject, double *d_refined_t, double *d_float_out);
+
 #ifdef __cplusplus
 }
 #endif

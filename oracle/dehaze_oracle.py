@@ -152,9 +152,12 @@ def bgr2ycrcb_u8(img):
     return np.clip(out, 0, 255).astype(np.uint8)
 
 
-def adaptiveExp_map(normI, w=15, B=None, r=40, eps=1e-3):
-    """BGDehaze.py:71-89."""
-    restored = RC_correction(normI, w, B)
+def adaptiveExp_tail(normI, restored, r=40, eps=1e-3, guard_s=False):
+    """BGDehaze.py:75-89, given RC_correction's output.  The uint8 casts at
+    :75-76 TRUNCATE, so this stage is ill-conditioned wherever restored*255
+    sits on an integer (the linearly mapped red channel does so routinely):
+    tests feed it the device's own `restored` to check the tail in isolation.
+    guard_s mirrors UWIP_DEHAZE_GUARD_S (S = 1 where it would be 0/0)."""
     R = (restored * 255).astype(np.uint8)
     I = (normI * 255).astype(np.uint8)
     YjCrCb = bgr2ycrcb_u8(R)
@@ -163,15 +166,25 @@ def adaptiveExp_map(normI, w=15, B=None, r=40, eps=1e-3):
     normYi = (YiCrCb - YiCrCb.min()) / (YiCrCb.max() - YiCrCb.min())
     Yi = normYi[:, :, 0]
     Yj = normYj[:, :, 0]
-    S = (Yj * Yi + 0.3 * Yi ** 2) / (Yj ** 2 + 0.3 * Yi ** 2)
-    refinedS = guided_filter(normYi, S, r, eps)
-    out = restored * refinedS[:, :, None]
-    return (out - out.min()) / (out.max() - out.min())
+    with np.errstate(divide="ignore", invalid="ignore"):
+        num, den = Yj * Yi + 0.3 * Yi ** 2, Yj ** 2 + 0.3 * Yi ** 2
+        S = num / den
+        if guard_s:
+            S = np.where(den == 0, 1.0, S)
+        refinedS = guided_filter(normYi, S, r, eps)
+        out = restored * refinedS[:, :, None]
+        return (out - out.min()) / (out.max() - out.min())
+
+
+def adaptiveExp_map(normI, w=15, B=None, r=40, eps=1e-3, guard_s=False):
+    """BGDehaze.py:71-89."""
+    return adaptiveExp_tail(normI, RC_correction(normI, w, B), r, eps, guard_s)
 
 
 def to_u8(restored):
     """cv2.imwrite(dest, restored*255) (main.py:19): convertTo(CV_8U) = RNE + saturate."""
-    return np.clip(np.rint(restored * 255), 0, 255).astype(np.uint8)
+    v = np.nan_to_num(restored * 255, nan=-1.0)          # cvRound(NaN) = INT_MIN -> saturates to 0
+    return np.clip(np.rint(v), 0, 255).astype(np.uint8)
 
 
 def bgdehaze_u8(I_u8, w=15, full=True):

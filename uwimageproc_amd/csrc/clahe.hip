@@ -452,7 +452,7 @@ int check_pair(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst
 
 int check_grid(uwip_ctx *ctx, int gx, int gy)
 {
-    UWIP_REQUIRE(ctx, gx >= 1 && gy >= 1 && gx <= 128 && gy <= 128, "tile grid must be in [1,128]");
+    UWIP_REQUIRE(ctx, gx >= 1 && gy >= 1 && gx <= 62 && gy <= 128, "tile grid must be in [1,62] x [1,128]");
     return UWIP_OK;
 }
 
