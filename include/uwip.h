@@ -141,6 +141,28 @@ int uwip_entropy(uwip_ctx *ctx, const uwip_batch_u8 *src, float *d_entropy);
 int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int residual_rule,
                       float *d_entropy);
 
+/* Parameter choice of modules/aclahe/python/ACLAHE.py:66-129 (host, pure; the
+ * reference does it with scipy, functions.py:49-93; the C++ module stops at
+ * comment stubs, aclahe.cpp:209-218).
+ * uwip_aclahe_knee: DerivadaY + DerivadaX + Curvatura on one 49-sample curve
+ *   (h_xs49 = clip limits 0.5..24.5, h_ys49 = entropies) -> arg-max index, or
+ *   -1 where scipy's curve_fit would raise.
+ * uwip_aclahe_select: h_entropy [frames][5][51] (the sweep table) -> per frame
+ *   h_bs (block size) and h_cl (clip limit = the largest of the five knee
+ *   indices, used as a clip limit as the reference does); h_knee (may be NULL)
+ *   [frames][5].  When 2*CL lies outside the swept grid the BS choice falls
+ *   back to the last swept clip limit; uwip_aclahe_auto evaluates it exactly. */
+int uwip_aclahe_knee(const float *h_xs49, const float *h_ys49, int32_t *index);
+int uwip_aclahe_select(const float *h_entropy, int frames, int32_t *h_bs, int32_t *h_cl,
+                       int32_t *h_knee);
+
+/* The whole aclahe stage on 8UC1 planes: sweep (aclahe.cpp:160-193), parameter
+ * choice (ACLAHE.py:66-129) and the final createCLAHE(CL,(BS,BS)).apply
+ * (python/main.py:19-20).  h_bs / h_cl (may be NULL): the chosen parameters.
+ * Synchronises the stream once (the choice is a host decision). */
+int uwip_aclahe_auto(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst,
+                     int residual_rule, int32_t *h_bs, int32_t *h_cl);
+
 /* ---- bgdehaze (D1-D6) ---------------------------------------------------- */
 /* All real-valued results are float64, as in the reference.  The input is the
  * uint8 BGR frame cv2.imread returns; normI = (I - min)/(max - min)

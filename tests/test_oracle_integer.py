@@ -245,3 +245,38 @@ def test_gray_and_blur(orc):
     lap = np.clip(lap, 0, 255).astype(np.float64)
     assert abs(orc.calcBlur(img) - np.float32(lap.std())) < 1e-4
     assert orc.calcBlur(synth.adversarial("constant", 16, 16)) == 0.0
+
+
+# ------------------------------------------------- C4: parameter choice ----
+def test_native_knee_matches_reference_golden():
+    """uwip_aclahe_select (MINPACK lmdif + not-a-knot spline restated in C++, host only)
+    against indices produced by the reference's own functions.py (tests/golden/aclahe_knee.npz)."""
+    import ctypes as C
+    import os
+    from uwimageproc_amd import _native as nat
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "aclahe_knee.npz"), allow_pickle=False)
+    tabs = np.ascontiguousarray(g["tables"], np.float32)
+    F = tabs.shape[0]
+    bs, cl, knee = (C.c_int32 * F)(), (C.c_int32 * F)(), (C.c_int32 * (5 * F))()
+    rc = nat.lib().uwip_aclahe_select(tabs.ctypes.data_as(C.POINTER(C.c_float)), F, bs, cl, knee)
+    assert rc == 0
+    assert np.array_equal(np.array(list(knee)).reshape(F, 5), g["idx"])
+    # CL = max of the five indices; BS = last arg-max of float16 entropies at clip limit CL
+    for f in range(F):
+        d = int(g["idx"][f].max())
+        assert cl[f] == d
+        ent = tabs[f][:, 2 * d].astype(np.float16)
+        assert bs[f] == (2, 4, 8, 16, 32)[int(np.nonzero(ent == ent.max())[0][-1])]
+
+
+def test_native_knee_matches_scipy_mirror(orc):
+    import ctypes as C
+    from uwimageproc_amd import _native as nat, aclahe
+    xs = (np.arange(51, dtype=np.float32) * 0.5)[1:50].copy()
+    for seed in (20, 21):
+        tab = orc.sweep(orc.bgr_to_v(synth.uw_frame(seed, 135, 240)))
+        for gi in range(5):
+            ys = np.ascontiguousarray(tab[gi][1:50], np.float32)
+            k = C.c_int32(0)
+            nat.lib().uwip_aclahe_knee(xs.ctypes.data_as(C.POINTER(C.c_float)), ys.ctypes.data_as(C.POINTER(C.c_float)), C.byref(k))
+            assert k.value == aclahe.knee_index(xs, ys)

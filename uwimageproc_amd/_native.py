@@ -74,6 +74,9 @@ SIGNATURES = {
     "uwip_clahe_luts": (C.c_int, [_P, _B, C.c_double, C.c_int, C.c_int, C.c_int, _P]),
     "uwip_entropy": (C.c_int, [_P, _B, _P]),
     "uwip_aclahe_sweep": (C.c_int, [_P, _B, C.c_int, _P]),
+    "uwip_aclahe_knee": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "uwip_aclahe_select": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "uwip_aclahe_auto": (C.c_int, [_P, _B, _B, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "uwip_dehaze_background_light": (C.c_int, [_P, _B, C.c_int, _P, _P]),
     "uwip_dehaze_transmission": (C.c_int, [_P, _B, _P, _P]),
     "uwip_guided_filter": (C.c_int, [_P, _B, _P, C.c_int, C.c_double, _P]),

@@ -660,3 +660,63 @@ UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int resi
     }
     return UWIP_OK;
 }
+
+int uwip_aclahe_select_internal(const float *h_entropy, int frames, int32_t *h_bs, int32_t *h_cl, int32_t *h_knee,
+                                int32_t *h_need_eval, const float *h_extra, const int32_t *h_extra_valid);
+
+// C3 + C4 + the final apply in one call: sweep -> (host) parameter choice -> per-frame CLAHE.
+// This is the whole "aclahe" stage of the pipe.  h_bs / h_cl receive the chosen parameters.
+UWIP_API int uwip_aclahe_auto(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int residual_rule,
+                              int32_t *h_bs, int32_t *h_cl)
+{
+    int rc = check_pair(ctx, src, dst);
+    if (rc) return rc;
+    if (src->frames == 0) return UWIP_OK;
+    UWIP_REQUIRE(ctx, !uwip_batch_empty(src), "aclahe of an empty image");
+    const int F = src->frames;
+    float *d_ent = (float *)uwip_ws(ctx, "auto.entropy", sizeof(float) * 255 * F);
+    float *h_ent = (float *)uwip_host_ws(ctx, "auto.entropy", sizeof(float) * 255 * F);
+    int32_t *h_par = (int32_t *)uwip_host_ws(ctx, "auto.params", sizeof(int32_t) * 4 * F + sizeof(float) * 5 * F + sizeof(double) * F);
+    if (!d_ent || !h_ent || !h_par) return UWIP_ERR_NOMEM;
+    rc = uwip_aclahe_sweep(ctx, src, residual_rule, d_ent);
+    if (rc) return rc;
+    UWIP_HIP(ctx, hipMemcpyAsync(h_ent, d_ent, sizeof(float) * 255 * F, hipMemcpyDeviceToHost, ctx->stream));
+    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));            // host decision point (ACLAHE.py:66-129)
+    int32_t *bs = h_par, *cl = h_par + F, *need = h_par + 2 * F, *valid = h_par + 3 * F;
+    float *extra = (float *)(h_par + 4 * F);
+    double *clip = (double *)(extra + 5 * F);
+    rc = uwip_aclahe_select_internal(h_ent, F, bs, cl, nullptr, need, nullptr, nullptr);
+    if (rc) return ctx->fail(rc, "aclahe select");
+    bool any = false;
+    for (int f = 0; f < F; ++f) { valid[f] = 0; any = any || need[f]; }
+    if (any) {
+        // clip limit outside the swept grid: evaluate the five block sizes at that clip limit (ACLAHE.py:102-112)
+        static const int BlockSize[5] = {2, 4, 8, 16, 32};
+        uint8_t *tmp = (uint8_t *)uwip_ws(ctx, "auto.tmp", (size_t)src->rows * src->cols);
+        float *d_e1 = (float *)uwip_ws(ctx, "auto.e1", sizeof(float) * 8);
+        if (!tmp || !d_e1) return UWIP_ERR_NOMEM;
+        for (int f = 0; f < F; ++f) {
+            if (!need[f]) continue;
+            uwip_batch_u8 one = *src;
+            one.data = (uint8_t *)src->data + (size_t)f * src->frame_stride;
+            one.frames = 1;
+            uwip_batch_u8 t1 = one;
+            t1.data = tmp; t1.step = (size_t)src->cols; t1.frame_stride = (size_t)src->rows * src->cols;
+            for (int g = 0; g < 5; ++g) {
+                rc = uwip_clahe(ctx, &one, &t1, (double)cl[f], BlockSize[g], BlockSize[g], residual_rule);
+                if (rc) return rc;
+                rc = uwip_entropy(ctx, &t1, d_e1 + g);
+                if (rc) return rc;
+            }
+            UWIP_HIP(ctx, hipMemcpyAsync(extra + (size_t)f * 5, d_e1, sizeof(float) * 5, hipMemcpyDeviceToHost, ctx->stream));
+            UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            valid[f] = 1;
+        }
+        rc = uwip_aclahe_select_internal(h_ent, F, bs, cl, nullptr, need, extra, valid);
+        if (rc) return ctx->fail(rc, "aclahe select");
+    }
+    for (int f = 0; f < F; ++f) clip[f] = (double)cl[f];
+    if (h_bs) for (int f = 0; f < F; ++f) h_bs[f] = bs[f];
+    if (h_cl) for (int f = 0; f < F; ++f) h_cl[f] = cl[f];
+    return uwip_clahe_per_frame(ctx, src, dst, clip, bs, residual_rule);
+}
