@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/s of the per-frame pipe on synthetic 1080p frames.
+
+  python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (bgdehaze -> histretch -> aclahe ->
+videostrip-overlap) over one batch of synthetic 1920x1080 uchar3 frames that is
+already resident in HBM.  Frames are independent units: with N > 1 every rank
+runs the same per-GPU batch on its own GPU (weak scaling, no data-path
+collective; torch.distributed is used only for the barrier and the max-over-
+ranks time).  Rank 0 prints ONE JSON line with the whole-job frames/s, the HBM
+roofline of the dominant kernel (timed live with HIP events on the launch
+stream) and the CPU baseline (the oracle, timed on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--rows", type=int, default=1080)
+    ap.add_argument("--cols", type=int, default=1920)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-rows", type=int, default=540)
+    ap.add_argument("--cpu-sample-cols", type=int, default=960)
+    return ap.parse_args()
+
+
+def cpu_baseline(rows, cols):
+    """The oracle (CPU restatement, kind = "port") on ONE frame of reduced size,
+    scaled to frames/s at the bench resolution by pixel count.  Single thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import _oracle
+    import dehaze_oracle as dz
+    from uwimageproc_amd import aclahe, synth
+    orc = _oracle.load()
+    img = synth.uw_frame(0, rows, cols)
+    t0 = time.time()
+    out = dz.bgdehaze_u8(img, 15, full=True) if rows >= 81 and cols >= 81 else img
+    t1 = time.time()
+    st, _ = orc.histretch(out, "RGB")
+    v = orc.bgr_to_v(st)
+    tab = orc.sweep(v)
+    bs, cl = aclahe.select_parameters(tab)
+    orc.clahe(v, float(cl), bs, bs)
+    t2 = time.time()
+    parts = {"dehaze_s": t1 - t0, "histretch_aclahe_s": t2 - t1}
+    extra = _oracle_overlap_time(orc, st, parts)
+    total = (t2 - t0) + extra
+    return total, parts
+
+
+def _oracle_overlap_time(orc, frame, parts):
+    if not hasattr(orc, "calcOverlap"):
+        return 0.0
+    t0 = time.time()
+    orc.calcOverlap(frame, frame)
+    dt = time.time() - t0
+    parts["overlap_s"] = dt
+    return dt
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback)"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    from uwimageproc_amd import synth
+    from uwimageproc_amd.pipeline import FramePipe
+
+    F, H, W = args.frames, args.rows, args.cols
+    pipe = FramePipe(local_rank, F, H, W)
+    # a few distinct synthetic frames, tiled to the batch (seed = 1234 + index)
+    distinct = min(F, 8)
+    base = synth.uw_stream(rank * 1000, distinct, H, W) if hasattr(synth, "uw_stream") else synth.uw_batch(rank * 1000, distinct, H, W)
+    reps = (F + distinct - 1) // distinct
+    src = torch.from_numpy(np.concatenate([base] * reps, axis=0)[:F]).to(dev)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        pipe.run(src)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pipe.run(src)
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel timing pass (HIP events on the launch stream, inside libuwip)
+    roof = None
+    kernels = {}
+    if rank == 0:
+        pipe.ctx.prof_reset()
+        pipe.ctx.prof_enable(True)
+        nprof = max(1, min(args.steps, 3))
+        for _ in range(nprof):
+            pipe.run(src)
+        torch.cuda.synchronize()
+        res = pipe.ctx.prof_results()
+        pipe.ctx.prof_enable(False)
+        kernels = {k: {"ms_per_step": ms / nprof, "launches_per_step": cnt / nprof} for k, (ms, cnt) in res.items()}
+        N = H * W
+        # the CLAHE kernel named by north_star: the final per-frame apply (read N + write N per frame)
+        if "k_clahe_apply" in res:
+            ms, cnt = res["k_clahe_apply"]
+            per_launch_bytes = 2.0 * N * F * nprof / cnt
+            avg_ms = ms / cnt
+            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "k_clahe_apply", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                    "algorithmic_bytes_per_launch": per_launch_bytes}
+
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline:
+            r, c = min(args.cpu_sample_rows, H), min(args.cpu_sample_cols, W)
+            secs, parts = cpu_baseline(r, c)
+            scale = (H * W) / float(r * c)
+            cpu = {"value": 1.0 / (secs * scale), "unit": "frames/s", "cores": 1, "kind": "port",
+                   "sample": f"1 frame {c}x{r} through the CPU oracle (numpy dehaze + C histretch/aclahe"
+                             f"{' + C overlap' if 'overlap_s' in parts else ''}), scaled by pixel count to {W}x{H}",
+                   "seconds": secs, "parts": parts}
+        total_frames = world * F * args.steps
+        line = {
+            "metric": "frames/sec whole-node, 1080p full pipe (dehaze+stretch+CLAHE+overlap)",
+            "value": total_frames / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8 (histretch/CLAHE), f64 (dehaze), f32+i8 (overlap)",
+            "data": "synthetic",
+            "config": {"workload": f"full pipe bgdehaze->histretch->aclahe->videostrip-overlap on {W}x{H} uchar3 frames",
+                       "frames_per_gpu_per_step": F, "stages": pipe.stages(), "parallelism": f"frame-batch x{world}"},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+            "kernels": kernels,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

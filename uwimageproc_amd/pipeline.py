@@ -45,6 +45,9 @@ class FramePipe:
         self.ctx.call("uwip_aclahe_auto", C.byref(vb), C.byref(ob), 0, self.h_bs, self.h_cl)
         self.params = list(zip(self.h_bs, self.h_cl))
 
+    def stages(self):
+        return ["bgdehaze(adaptiveExp_map,w=15)", "histretch(RGB,2/98)", "aclahe(sweep+select+apply on V)"]
+
     def run(self, src: torch.Tensor):
         self.stage_dehaze(src)
         self.stage_histretch()
