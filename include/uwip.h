@@ -201,6 +201,60 @@ int uwip_guided_filter(uwip_ctx *ctx, const uwip_batch_u8 *guide, const double *
 int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batch_u8 *out, int w, int flags,
                 const double *d_B_inject, double *d_refined_t, double *d_float_out);
 
+/* ---- videostrip overlap (V1-V5) -------------------------------------------- */
+/* calcOverlap(keyframe*, Mat), modules/videostrip/src/videostrip.cpp:192-289, split
+ * at the point where the reference caches a key frame's keypoints/descriptors in
+ * `struct keyframe` (videostrip.hpp:62-68; kframe->new_img, :209-213):
+ *   uwip_overlap_detect   resize to 640 wide (main.cpp:242,311) + BGR2GRAY + detect + describe
+ *                         for a batch of frames, into slots of an opaque feature set;
+ *   uwip_overlap_match    kNN(2) match (:229-231), ratio test (:233-242), homography (:270),
+ *                         overlapArea (:280) for a list of (object slot, key slot) pairs.
+ * The detector/descriptor/matcher are the AKAZE-style / M-LDB / Hamming design that
+ * BASELINE.json's north_star names in place of the reference's OpenCV-contrib SURF +
+ * L2 matcher (DESIGN.md "overlap stage"); the dense distance matrix runs on i8 MFMA. */
+typedef struct uwip_features uwip_features;
+
+#define UWIP_MAX_KEYPOINTS 2048
+/* keypoint record returned by uwip_features_download (32 bytes) */
+typedef struct uwip_keypoint {
+    float   x, y;        /* sub-pixel position in the 640-wide working image */
+    float   response;    /* scale-normalised determinant of the Hessian */
+    int32_t level;       /* evolution level 0..3 */
+    int32_t xi, yi;      /* integer extremum position */
+    int32_t pad0, pad1;
+} uwip_keypoint;
+
+int uwip_features_create(uwip_ctx *ctx, int max_frames, uwip_features **out);
+int uwip_features_destroy(uwip_features *feats);
+/* working size for a rows x cols frame: cv::resize(frame, Size(), f, f), f = 640/cols */
+int uwip_overlap_working_size(int rows, int cols, int *orows, int *ocols);
+/* frames: full-resolution CV_8UC3 BGR (resized inside) or CV_8UC1 planes already at the
+ * working size.  Fills slots [first_slot, first_slot + frames->frames). */
+int uwip_overlap_detect(uwip_ctx *ctx, const uwip_batch_u8 *frames, uwip_features *feats, int first_slot);
+/* parity taps: one slot's keypoints (uwip_keypoint[2048]) / packed 64-byte descriptors; and the
+ * scale-space images of frame `frame` of the most recent uwip_overlap_detect call (host buffers
+ * of rows*cols floats, any may be NULL). */
+int uwip_features_download(uwip_ctx *ctx, const uwip_features *feats, int slot, void *h_kps,
+                           uint8_t *h_desc, int32_t *h_count);
+int uwip_overlap_debug_level(uwip_ctx *ctx, int frame, int level, int rows, int cols, float *h_Lt,
+                             float *h_Lx, float *h_Ly, float *h_Ldet, float *h_kcontrast);
+/* h_pair_q / h_pair_t: host arrays of slot indices (query = object frame in fq, train = key
+ * frame in ft).  d_ratio [npairs]: the overlap ratio, or -2.0 when fewer than 4 good matches
+ * survive or no homography is found (videostrip.cpp:252-256,272).  videoWidth / videoHeight
+ * are the reference's globals (main.cpp:238-239).  Optional device outputs:
+ * d_info [npairs][8] = {nkp_obj, nkp_key, ngood, ninliers, overlap pixels, 0,0,0};
+ * d_H [npairs][9]; d_match_idx / d_match_dist [npairs][2048][2] (the kNN(2) result). */
+int uwip_overlap_match(uwip_ctx *ctx, const uwip_features *fq, const uwip_features *ft,
+                       const int32_t *h_pair_q, const int32_t *h_pair_t, int npairs, int videoWidth,
+                       int videoHeight, uint32_t seed, float *d_ratio, int32_t *d_info, double *d_H,
+                       int32_t *d_match_idx, int32_t *d_match_dist);
+/* overlapArea(Mat H), videostrip.cpp:291-319, for n row-major 3x3 double homographies. */
+int uwip_overlapArea(uwip_ctx *ctx, const double *d_H, int n, int videoWidth, int videoHeight,
+                     float *d_ratio, int32_t *d_count);
+/* calcBlur(Mat frame), videostrip.cpp:170-184, on BGR frames (the reference passes the
+ * resized frame, main.cpp:338,355): d_blur [frames]. */
+int uwip_calcBlur(uwip_ctx *ctx, const uwip_batch_u8 *frames, float *d_blur);
+
 #ifdef __cplusplus
 }
 #endif

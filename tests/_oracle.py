@@ -44,6 +44,89 @@ class Oracle:
         L.orc_calcBlur.restype = C.c_float
         L.orc_calcBlur.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t]
 
+        self.KP = np.dtype([("x", "f4"), ("y", "f4"), ("response", "f4"), ("level", "i4"), ("xi", "i4"), ("yi", "i4"),
+                            ("pad0", "i4"), ("pad1", "i4")])
+        L.orc_resize_dims.restype = None
+        L.orc_resize_dims.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_resize_gray.restype = None
+        L.orc_resize_gray.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, u8p, C.c_void_p]
+        L.orc_detect_describe.restype = C.c_int
+        L.orc_detect_describe.argtypes = [u8p, C.c_int, C.c_int, C.c_void_p, u8p, C.POINTER(C.c_float)]
+        L.orc_scale_space_level.restype = None
+        L.orc_scale_space_level.argtypes = [u8p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p]
+        L.orc_match_knn2.restype = None
+        L.orc_match_knn2.argtypes = [u8p, C.c_int, u8p, C.c_int, i32p, i32p]
+        L.orc_ratio_test.restype = C.c_int
+        L.orc_ratio_test.argtypes = [i32p, i32p, C.c_int, C.c_int, i32p, i32p]
+        L.orc_find_homography.restype = C.c_int
+        L.orc_find_homography.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
+        L.orc_overlapArea.restype = C.c_float
+        L.orc_overlapArea.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_int32)]
+        L.orc_calcOverlap.restype = C.c_float
+        L.orc_calcOverlap.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_uint32,
+                                      C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+
+    # ---- overlap wrappers ----
+    def resize_dims(self, rows, cols, target_w=640):
+        a, b = C.c_int(0), C.c_int(0)
+        self.lib.orc_resize_dims(rows, cols, target_w, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def resize_gray(self, img):
+        img = np.ascontiguousarray(img)
+        oh, ow = self.resize_dims(img.shape[0], img.shape[1])
+        g = np.zeros((oh, ow), np.uint8)
+        self.lib.orc_resize_gray(img, img.shape[0], img.shape[1], img.strides[0], oh, ow, g, None)
+        return g
+
+    def detect_describe(self, gray):
+        gray = np.ascontiguousarray(gray)
+        kps = np.zeros(2048, self.KP)
+        desc = np.zeros((2048, 64), np.uint8)
+        kc = C.c_float(0)
+        n = self.lib.orc_detect_describe(gray, gray.shape[0], gray.shape[1], kps.ctypes.data, desc, C.byref(kc))
+        return kps[:n].copy(), desc[:n].copy(), kc.value
+
+    def scale_space_level(self, gray, level):
+        gray = np.ascontiguousarray(gray)
+        outs = [np.zeros(gray.shape, np.float32) for _ in range(4)]
+        self.lib.orc_scale_space_level(gray, gray.shape[0], gray.shape[1], level, *outs)
+        return outs   # Lt, Lx, Ly, Ldet
+
+    def match_knn2(self, dq, dt):
+        dq, dt = np.ascontiguousarray(dq), np.ascontiguousarray(dt)
+        idx = np.full((max(len(dq), 1), 2), -1, np.int32)
+        dist = np.full((max(len(dq), 1), 2), -1, np.int32)
+        self.lib.orc_match_knn2(dq.reshape(-1), len(dq), dt.reshape(-1), len(dt), idx.reshape(-1), dist.reshape(-1))
+        return idx[:len(dq)], dist[:len(dq)]
+
+    def ratio_test(self, idx, dist, nt):
+        nq = len(idx)
+        gq, gt = np.zeros(max(nq, 1), np.int32), np.zeros(max(nq, 1), np.int32)
+        n = self.lib.orc_ratio_test(np.ascontiguousarray(idx).reshape(-1), np.ascontiguousarray(dist).reshape(-1), nq, nt, gq, gt)
+        return gq[:n], gt[:n]
+
+    def find_homography(self, ox, oy, sx, sy, w, h, seed=1):
+        H = (C.c_double * 9)()
+        a = [np.ascontiguousarray(v, np.float32) for v in (ox, oy, sx, sy)]
+        n = self.lib.orc_find_homography(a[0], a[1], a[2], a[3], len(a[0]), w, h, seed, H)
+        return n, np.array(list(H)).reshape(3, 3)
+
+    def overlapArea(self, H, vw, vh):
+        Hc = (C.c_double * 9)(*np.asarray(H, np.float64).reshape(-1))
+        cnt = C.c_int32(0)
+        r = self.lib.orc_overlapArea(Hc, vw, vh, C.byref(cnt))
+        return float(r), cnt.value
+
+    def calcOverlap(self, key, obj, vw=None, vh=None, seed=1):
+        key, obj = np.ascontiguousarray(key), np.ascontiguousarray(obj)
+        vw = key.shape[1] if vw is None else vw
+        vh = key.shape[0] if vh is None else vh
+        info = (C.c_int32 * 8)()
+        H = (C.c_double * 9)()
+        r = self.lib.orc_calcOverlap(key, obj, key.shape[0], key.shape[1], key.strides[0], vw, vh, seed, info, H)
+        return float(r), list(info)[:5], np.array(list(H)).reshape(3, 3)
+
     # ---- numpy-friendly wrappers ----
     def numChannel(self, c): return self.lib.orc_numChannel(c.encode()[:1])
     def numSpace(self, c): return self.lib.orc_numSpace(c.encode()[:1])

@@ -1,0 +1,154 @@
+"""GPU parity: videostrip overlap path (through the C ABI) vs oracle/uwip_oracle_overlap.c.
+Scale space, keypoints, descriptors, kNN(2) matches, overlap pixel counts: exact.
+Homography / ratio: same deterministic algorithm in float64 -> compared at 1e-9 / 1e-6,
+with the SURVEY's +-0.01 on the ratio as the stated acceptance bound."""
+import numpy as np
+import pytest
+import torch
+
+from uwimageproc_amd import synth, videostrip as vs
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.fixture(scope="module")
+def stream():
+    return synth.uw_stream(0, 4, 1080, 1920)
+
+
+def test_working_size(ctx, orc):
+    import ctypes as C
+    for rows, cols in ((1080, 1920), (2160, 3840), (480, 640), (720, 1280), (600, 800)):
+        a, b = C.c_int(0), C.c_int(0)
+        ctx._l.uwip_overlap_working_size(rows, cols, C.byref(a), C.byref(b))
+        assert (a.value, b.value) == orc.resize_dims(rows, cols)
+    assert orc.resize_dims(1080, 1920) == (360, 640)
+
+
+def test_scale_space_bit_exact(ctx, orc, stream):
+    import ctypes as C
+    gray = orc.resize_gray(stream[0])
+    f = vs.Features(ctx, 1)
+    f.detect(_dev(stream[0]))
+    h, w = gray.shape
+    for lv in range(4):
+        got = [np.zeros((h, w), np.float32) for _ in range(4)]
+        kc = C.c_float(0)
+        ctx.call("uwip_overlap_debug_level", 0, lv, h, w, *[C.c_void_p(g.ctypes.data) for g in got], C.byref(kc))
+        exp = orc.scale_space_level(gray, lv)
+        for name, a, b in zip(("Lt", "Lx", "Ly", "Ldet"), got, exp):
+            assert np.array_equal(a, b), (lv, name, np.abs(a - b).max())
+    _, _, kc_o = orc.detect_describe(gray)
+    assert kc.value == kc_o
+
+
+@pytest.mark.parametrize("shape", [(1080, 1920), (480, 640), (600, 800)])
+def test_keypoints_and_descriptors_exact(ctx, orc, shape):
+    frames = synth.uw_stream(3, 2, *shape)
+    f = vs.Features(ctx, 2)
+    f.detect(_dev(frames))
+    for s in range(2):
+        kps, desc = f.download(s)
+        ek, ed, _ = orc.detect_describe(orc.resize_gray(frames[s]))
+        assert len(kps) == len(ek) and len(kps) > 30
+        for fld in ("xi", "yi", "level"):
+            assert np.array_equal(kps[fld], ek[fld]), fld
+        for fld in ("x", "y", "response"):
+            assert np.array_equal(kps[fld], ek[fld]), fld
+        assert np.array_equal(desc, ed)
+
+
+def test_gray_plane_input(ctx, orc, stream):
+    gray = orc.resize_gray(stream[1])
+    f = vs.Features(ctx, 1)
+    f.detect(_dev(gray))
+    kps, desc = f.download(0)
+    ek, ed, _ = orc.detect_describe(gray)
+    assert np.array_equal(kps["x"], ek["x"]) and np.array_equal(desc, ed)
+
+
+def test_matches_exact_and_ratio(ctx, orc, stream):
+    f = vs.Features(ctx, 4)
+    f.detect(_dev(stream))
+    vs.videoWidth, vs.videoHeight = 640, 480
+    pq, pt = [1, 2, 3, 1], [0, 0, 0, 1]
+    res = vs.match_pairs(ctx, f, f, pq, pt, 640, 480, seed=7, want_matches=True)
+    idx, dist = res["idx"].cpu().numpy(), res["dist"].cpu().numpy()
+    feats = [f.download(s) for s in range(4)]
+    for p, (q, t) in enumerate(zip(pq, pt)):
+        eidx, edist = orc.match_knn2(feats[q][1], feats[t][1])
+        nq = len(feats[q][0])
+        assert np.array_equal(idx[p, :nq], eidx) and np.array_equal(dist[p, :nq], edist)
+        gq, gt = orc.ratio_test(eidx, edist, len(feats[t][0]))
+        info = res["info"].cpu().numpy()[p]
+        assert info[0] == nq and info[1] == len(feats[t][0]) and info[2] == len(gq)
+        kq, kt = feats[q][0], feats[t][0]
+        ninl, H = orc.find_homography(kq["x"][gq], kq["y"][gq], kt["x"][gt], kt["y"][gt], 640, 360, seed=7)
+        assert info[3] == ninl
+        Hg = res["H"].cpu().numpy()[p]
+        assert np.abs(Hg - H).max() <= 1e-9 * max(1.0, np.abs(H).max())
+        er, ecnt = orc.overlapArea(H, 640, 480)
+        assert info[4] == ecnt
+        assert abs(float(res["ratio"].cpu()[p]) - er) <= 1e-6
+    # identical frames overlap completely
+    assert abs(float(res["ratio"].cpu()[3]) - 1.0) <= 0.01
+
+
+def test_calcOverlap_end_to_end_and_known_translation(ctx, orc, stream):
+    vs.videoWidth, vs.videoHeight = 640, 480        # consistent-area variant (B-8)
+    kf = vs.keyframe(ctx, _dev(stream[0]))
+    sx, sy = synth.uw_stream_shift(1920)
+    for j in (1, 2, 3):
+        r = vs.calcOverlap(ctx, kf, _dev(stream[j]), seed=1)
+        er, info, H = orc.calcOverlap(stream[0], stream[j], 640, 480, seed=1)
+        assert abs(r - er) <= 1e-6
+        # ground truth: pure translation by j*(sx, sy)/3 working pixels
+        tx, ty = j * sx / 3.0, j * sy / 3.0
+        true_ratio = (640 - tx) * (360 - ty) / (640 * 480 + 640 * 480 - (640 - tx) * (360 - ty))
+        assert abs(H[0, 2] - tx) < 1.0 and abs(H[1, 2] - ty) < 1.0
+        assert r > 0
+    # as written (B-8): full-resolution area in the denominator -> ratio <= 0.148 for 1080p
+    vs.videoWidth, vs.videoHeight = 1920, 1080
+    r = vs.calcOverlap(ctx, kf, _dev(stream[1]))
+    er, _, _ = orc.calcOverlap(stream[0], stream[1], 1920, 1080, seed=1)
+    assert abs(r - er) <= 1e-6 and r <= 0.148
+
+
+def test_sentinels(ctx, orc):
+    vs.videoWidth, vs.videoHeight = 640, 480
+    flat = np.full((480, 640, 3), 90, np.uint8)                 # no keypoints -> -2.0
+    kf = vs.keyframe(ctx, _dev(flat))
+    assert vs.calcOverlap(ctx, kf, _dev(flat)) == -2.0
+    assert orc.calcOverlap(flat, flat, 640, 480)[0] == -2.0
+    kf2 = vs.keyframe(ctx, torch.zeros((0, 0, 3), dtype=torch.uint8, device="cuda"))
+    assert vs.calcOverlap(ctx, kf2, _dev(flat)) == -1.0        # empty image -> -1
+
+
+@pytest.mark.parametrize("H", [
+    np.eye(3), [[1, 0, 40.5], [0, 1, -20.25], [0, 0, 1]], [[0.9, 0.05, 100], [-0.04, 1.1, 50], [1e-5, -2e-5, 1]],
+    [[1, 0, 700], [0, 1, 0], [0, 0, 1]], [[1.2, 0.3, -200], [0.1, 0.8, -100], [1e-4, 1e-4, 1]],
+    [[-1, 0, 640], [0, -1, 480], [0, 0, 1]],
+])
+def test_overlapArea_exact(ctx, orc, H):
+    for vw, vh in ((640, 480), (1920, 1080)):
+        vs.videoWidth, vs.videoHeight = vw, vh
+        er, _ = orc.overlapArea(H, vw, vh)
+        assert abs(vs.overlapArea(ctx, H) - er) <= 1e-7
+
+
+def test_overlapArea_identity_is_one(ctx):
+    vs.videoWidth, vs.videoHeight = 640, 480
+    # the 640x480 rectangle rasterised into a 480x640 mask: the x = 640 / y = 480 edges clip away
+    assert abs(vs.overlapArea(ctx, np.eye(3)) - 1.0) < 1e-6
+
+
+def test_calcBlur(ctx, orc):
+    frames = synth.uw_stream(5, 3, 360, 640)
+    b = vs.calcBlur(ctx, _dev(frames)).cpu().numpy()
+    for f in range(3):
+        assert abs(b[f] - orc.calcBlur(frames[f])) <= 1e-4
+    assert vs.calcBlur(ctx, _dev(np.full((32, 32, 3), 9, np.uint8))) == 0.0

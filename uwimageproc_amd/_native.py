@@ -81,6 +81,16 @@ SIGNATURES = {
     "uwip_dehaze_transmission": (C.c_int, [_P, _B, _P, _P]),
     "uwip_guided_filter": (C.c_int, [_P, _B, _P, C.c_int, C.c_double, _P]),
     "uwip_dehaze": (C.c_int, [_P, _B, _B, C.c_int, C.c_int, _P, _P, _P]),
+    "uwip_features_create": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
+    "uwip_features_destroy": (C.c_int, [_P]),
+    "uwip_overlap_working_size": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "uwip_overlap_detect": (C.c_int, [_P, _B, _P, C.c_int]),
+    "uwip_features_download": (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(C.c_int32)]),
+    "uwip_overlap_debug_level": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "uwip_overlap_match": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
+                                     C.c_uint32, _P, _P, _P, _P, _P]),
+    "uwip_overlapArea": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "uwip_calcBlur": (C.c_int, [_P, _B, _P]),
 }
 
 

@@ -1,0 +1,1498 @@
+// videostrip overlap path for gfx950.
+//
+// calcOverlap (modules/videostrip/src/videostrip.cpp:192-289) = resize ->
+// gray -> detect+describe -> brute-force kNN(2) -> ratio test -> RANSAC
+// homography -> overlapArea.  The reference delegates detect/describe/match to
+// OpenCV-contrib SURF + L2 BFMatcher; BASELINE.json's north_star replaces them
+// with an AKAZE-style detector, binary descriptors and a Hamming matcher whose
+// dense distance matrix runs on MFMA.  The algorithm is specified in
+// DESIGN.md ("overlap stage") and restated independently in
+// oracle/uwip_oracle_overlap.c; every float kernel here keeps that
+// specification's operation order (-ffp-contract=off), so keypoints,
+// descriptors and matches are bit-exact against the oracle.
+//
+// Everything is batched: one launch covers all frames (grid.z), because a
+// 640x360 working image is far too small to fill 256 CUs on its own.
+#include "uwip_internal.hpp"
+#include "device_utils.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+constexpr int NLEV = 4;
+constexpr int MAXKP = 2048;
+constexpr int DESC_BYTES = 64;     // packed bits
+constexpr int DESC_K = 512;        // unpacked 0/1 bytes for the i8 MFMA
+constexpr int BORDER = 8;
+constexpr float DTHRESH = 0.001f;
+constexpr int RANSAC_ITERS = 512;
+constexpr int TW = 640, TH = 480;  // TARGET_WIDTH / TARGET_HEIGHT (videostrip.hpp:48-49)
+
+const float H_SIGMA[NLEV] = {1.6f, 2.2627417f, 3.2f, 4.5254834f};
+const int H_SSIZE[NLEV] = {2, 3, 5, 7};
+__constant__ int D_SSIZE[NLEV] = {2, 3, 5, 7};
+
+struct Keypoint {
+    float x, y, response;
+    int32_t level, xi, yi, pad0, pad1;
+};
+
+struct ConvK {
+    int ks;
+    float k[16];
+};
+
+}  // namespace
+
+// The opaque feature set: everything calcOverlap caches in `struct keyframe`
+// (videostrip.hpp:62-68: keypoints + descriptors of a frame), for a batch of frames.
+struct uwip_features {
+    uwip_ctx *ctx = nullptr;
+    int capacity = 0;      // frames
+    int frames = 0;        // valid frames
+    int w = 0, h = 0;      // working (640-wide) size
+    Keypoint *d_kp = nullptr;      // [capacity][MAXKP]
+    uint8_t *d_desc = nullptr;     // [capacity][MAXKP][64]   packed
+    int8_t *d_bits = nullptr;      // [capacity][MAXKP][512]  0/1 bytes (MFMA operand)
+    int32_t *d_pop = nullptr;      // [capacity][MAXKP]       popcounts
+    int32_t *d_n = nullptr;        // [capacity]              keypoint counts
+};
+
+namespace {
+
+// ---- resize (INTER_LINEAR, 8UC3, fixed point) + BGR2GRAY + /255 ---------------------------
+__global__ __launch_bounds__(256) void k_ov_resize_gray(const uint8_t *__restrict__ src, size_t step, size_t fs,
+                                                       int rows, int cols, int oh, int ow,
+                                                       const int *__restrict__ xo, const short *__restrict__ xa,
+                                                       const short *__restrict__ xb, const int *__restrict__ yo,
+                                                       const short *__restrict__ ya, const short *__restrict__ yb,
+                                                       uint8_t *__restrict__ gray, float *__restrict__ L0)
+{
+    const int f = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= ow || y >= oh) return;
+    const uint8_t *b = src + (size_t)f * fs;
+    const int sy = yo[y], sy1 = sy + 1 < rows ? sy + 1 : sy;
+    const uint8_t *r0 = b + (size_t)sy * step, *r1 = b + (size_t)sy1 * step;
+    const int sx = xo[x], sx1 = sx + 1 < cols ? sx + 1 : sx;
+    const int a0 = xa[x], a1 = xb[x], b0 = ya[y], b1 = yb[y];
+    int px[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int S0 = r0[sx * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+        const int S1 = r1[sx * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+        const int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        px[c] = min(max(v, 0), 255);
+    }
+    const int g = (px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + 8192) >> 14;
+    const size_t o = ((size_t)f * oh + y) * ow + x;
+    gray[o] = (uint8_t)g;
+    L0[o] = (float)g / 255.0f;
+}
+
+// gray u8 (already at working size) -> L0
+__global__ void k_ov_gray_to_L0(const uint8_t *__restrict__ gray, float *__restrict__ L0, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) L0[i] = (float)gray[i] / 255.0f;
+}
+
+// ---- separable Gaussian, reflect-101 border ----------------------------------------------
+template <bool ALONG_X>
+__global__ __launch_bounds__(256) void k_ov_conv(const float *__restrict__ in, float *__restrict__ out, int h, int w,
+                                                ConvK K)
+{
+    const int f = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float *I = in + (size_t)f * h * w;
+    const int r = K.ks / 2;
+    float acc = 0.0f;
+    for (int i = 0; i < K.ks; ++i) {
+        const float v = ALONG_X ? I[(size_t)y * w + reflect101(x + i - r, w)] : I[(size_t)reflect101(y + i - r, h) * w + x];
+        acc = acc + K.k[i] * v;
+    }
+    out[((size_t)f * h + y) * w + x] = acc;
+}
+
+__device__ __forceinline__ void scharr_at(const float *I, int h, int w, int y, int x, float &gx, float &gy)
+{
+    const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h), xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+    const float a0 = I[(size_t)ym * w + xm], a1 = I[(size_t)ym * w + x], a2 = I[(size_t)ym * w + xp];
+    const float b0 = I[(size_t)y * w + xm], b2 = I[(size_t)y * w + xp];
+    const float c0 = I[(size_t)yp * w + xm], c1 = I[(size_t)yp * w + x], c2 = I[(size_t)yp * w + xp];
+    float t0 = 3.0f * (a2 - a0), t1 = 10.0f * (b2 - b0), t2 = 3.0f * (c2 - c0);
+    gx = (t0 + t1) + t2;
+    t0 = 3.0f * (c0 - a0); t1 = 10.0f * (c1 - a1); t2 = 3.0f * (c2 - a2);
+    gy = (t0 + t1) + t2;
+}
+
+// ---- contrast factor: 70th percentile of the gradient-magnitude histogram ------------------
+// PASS 0: per-frame max (float bits as uint, values >= 0).  PASS 1: 300-bin histogram.
+template <int PASS>
+__global__ __launch_bounds__(256) void k_ov_kc(const float *__restrict__ Lsm, int h, int w, uint32_t *__restrict__ hmax_bits,
+                                              uint32_t *__restrict__ hist /*[F][304]*/)
+{
+    __shared__ uint32_t s_hist[304];
+    const int f = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const float *I = Lsm + (size_t)f * h * w;
+    if (PASS == 1) {
+        for (int i = threadIdx.x; i < 304; i += 256) s_hist[i] = 0;
+        __syncthreads();
+    }
+    const bool in = x >= 1 && x < w - 1 && y >= 1 && y < h - 1;
+    float m = 0.0f;
+    if (in) {
+        float gx, gy;
+        scharr_at(I, h, w, y, x, gx, gy);
+        m = sqrtf(gx * gx + gy * gy);
+    }
+    if (PASS == 0) {
+        uint32_t b = __float_as_uint(m);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
+        if ((threadIdx.x & 63) == 0 && b) atomicMax(&hmax_bits[f], b);
+    } else {
+        const float hmax = __uint_as_float(hmax_bits[f]);
+        if (in && m != 0.0f && hmax != 0.0f) {
+            int nbin = (int)floorf(300.0f * (m / hmax));
+            if (nbin >= 300) nbin = 299;
+            atomicAdd(&s_hist[nbin], 1u);
+            atomicAdd(&s_hist[300], 1u);       // npoints
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 301; i += 256)
+            if (s_hist[i]) atomicAdd(&hist[(size_t)f * 304 + i], s_hist[i]);
+    }
+}
+
+__global__ void k_ov_kc_final(const uint32_t *__restrict__ hmax_bits, const uint32_t *__restrict__ hist, float *__restrict__ kc, int F)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    const float hmax = __uint_as_float(hmax_bits[f]);
+    if (hmax == 0.0f) { kc[f] = 0.03f; return; }
+    const uint32_t *hh = hist + (size_t)f * 304;
+    const int npoints = (int)hh[300];
+    const int nthreshold = (int)((float)npoints * 0.7f);
+    int k = 0, nelements = 0;
+    for (k = 0; nelements < nthreshold && k < 300; k++) nelements += (int)hh[k];
+    kc[f] = nelements < nthreshold ? 0.03f : hmax * ((float)k / 300.0f);
+}
+
+// ---- Perona-Malik g2 conductivity ------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ov_flow(const float *__restrict__ Lsm, const float *__restrict__ kc, float *__restrict__ flow, int h, int w)
+{
+    const int f = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float k = kc[f];
+    const float inv_k = 1.0f / (k * k);
+    float gx, gy;
+    scharr_at(Lsm + (size_t)f * h * w, h, w, y, x, gx, gy);
+    flow[((size_t)f * h + y) * w + x] = 1.0f / (1.0f + (gx * gx + gy * gy) * inv_k);
+}
+
+// ---- one explicit FED diffusion step ----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ov_fed(const float *__restrict__ Lin, const float *__restrict__ cin, float *__restrict__ out,
+                                               int h, int w, float tau)
+{
+    const int f = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float *L = Lin + (size_t)f * h * w, *c = cin + (size_t)f * h * w;
+    const float step = 0.5f * tau;
+    const int ym = y > 0 ? y - 1 : 0, yp = y < h - 1 ? y + 1 : h - 1;
+    const int xm = x > 0 ? x - 1 : 0, xp = x < w - 1 ? x + 1 : w - 1;
+    const size_t i = (size_t)y * w + x;
+    const float xpos = (c[i] + c[(size_t)y * w + xp]) * (L[(size_t)y * w + xp] - L[i]);
+    const float xneg = (c[(size_t)y * w + xm] + c[i]) * (L[i] - L[(size_t)y * w + xm]);
+    const float ypos = (c[i] + c[(size_t)yp * w + x]) * (L[(size_t)yp * w + x] - L[i]);
+    const float yneg = (c[(size_t)ym * w + x] + c[i]) * (L[i] - L[(size_t)ym * w + x]);
+    float d = xpos - xneg;
+    d = d + ypos;
+    d = d - yneg;
+    out[(size_t)f * h * w + i] = L[i] + step * d;
+}
+
+// ---- scale-s first derivative (taps at -s, 0, +s) ------------------------------------------------
+__device__ __forceinline__ float deriv_at(const float *I, int h, int w, int y, int x, int s, bool along_x)
+{
+    const float wgt = 10.0f / 3.0f;
+    const float norm = 1.0f / (2.0f * (float)s * (wgt + 2.0f));
+    const float wn = wgt * norm;
+    const int ym = reflect101(y - s, h), yp = reflect101(y + s, h);
+    const int xm = reflect101(x - s, w), xp = reflect101(x + s, w);
+    float t0, t1, t2;
+    if (along_x) {
+        t0 = norm * (I[(size_t)ym * w + xp] - I[(size_t)ym * w + xm]);
+        t1 = wn * (I[(size_t)y * w + xp] - I[(size_t)y * w + xm]);
+        t2 = norm * (I[(size_t)yp * w + xp] - I[(size_t)yp * w + xm]);
+    } else {
+        t0 = norm * (I[(size_t)yp * w + xm] - I[(size_t)ym * w + xm]);
+        t1 = wn * (I[(size_t)yp * w + x] - I[(size_t)ym * w + x]);
+        t2 = norm * (I[(size_t)yp * w + xp] - I[(size_t)ym * w + xp]);
+    }
+    return (t0 + t1) + t2;
+}
+
+__global__ __launch_bounds__(256) void k_ov_deriv1(const float *__restrict__ Lsm, float *__restrict__ Lx, float *__restrict__ Ly, int h, int w, int s)
+{
+    const int f = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float *I = Lsm + (size_t)f * h * w;
+    const size_t o = ((size_t)f * h + y) * w + x;
+    Lx[o] = deriv_at(I, h, w, y, x, s, true);
+    Ly[o] = deriv_at(I, h, w, y, x, s, false);
+}
+
+__global__ __launch_bounds__(256) void k_ov_ldet(const float *__restrict__ Lx, const float *__restrict__ Ly, float *__restrict__ Ldet, int h, int w, int s)
+{
+    const int f = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float *X = Lx + (size_t)f * h * w, *Y = Ly + (size_t)f * h * w;
+    const float lxx = deriv_at(X, h, w, y, x, s, true);
+    const float lyy = deriv_at(Y, h, w, y, x, s, false);
+    const float lxy = deriv_at(X, h, w, y, x, s, false);
+    const float ss = (float)(s * s), s4 = ss * ss;
+    Ldet[((size_t)f * h + y) * w + x] = (lxx * lyy - lxy * lxy) * s4;
+}
+
+// ---- extrema: candidate response map over all levels ------------------------------------------------
+// Ldet: [F][NLEV][h][w]; cand: same shape, response or 0
+__global__ __launch_bounds__(256) void k_ov_extrema(const float *__restrict__ Ldet, float *__restrict__ cand, int h, int w)
+{
+    const int f = blockIdx.z / NLEV, lv = blockIdx.z % NLEV;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const size_t n = (size_t)h * w;
+    const float *D = Ldet + ((size_t)f * NLEV + lv) * n;
+    float out = 0.0f;
+    if (x >= BORDER && x < w - BORDER && y >= BORDER && y < h - BORDER) {
+        const float v = D[(size_t)y * w + x];
+        bool ok = v > DTHRESH;
+        if (ok) {
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx)
+                    if ((dx != 0 || dy != 0) && !(v > D[(size_t)(y + dy) * w + x + dx])) ok = false;
+        }
+        for (int o = -1; o <= 1 && ok; o += 2) {
+            const int l2 = lv + o;
+            if (l2 < 0 || l2 >= NLEV) continue;
+            const float *E = Ldet + ((size_t)f * NLEV + l2) * n;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx)
+                    if (!(v > E[(size_t)(y + dy) * w + x + dx])) ok = false;
+        }
+        if (ok) {
+            // candidates that the sub-pixel refinement would discard are dropped here, so that
+            // the top-K selection sees exactly the oracle's candidate list
+            const float vxp = D[(size_t)y * w + x + 1], vxm = D[(size_t)y * w + x - 1];
+            const float vyp = D[(size_t)(y + 1) * w + x], vym = D[(size_t)(y - 1) * w + x];
+            const float Dx = 0.5f * (vxp - vxm), Dy = 0.5f * (vyp - vym);
+            const float Dxx = (vxp + vxm) - 2.0f * v, Dyy = (vyp + vym) - 2.0f * v;
+            const float Dxy = 0.25f * (D[(size_t)(y + 1) * w + x + 1] + D[(size_t)(y - 1) * w + x - 1]) -
+                              0.25f * (D[(size_t)(y + 1) * w + x - 1] + D[(size_t)(y - 1) * w + x + 1]);
+            const float det = Dxx * Dyy - Dxy * Dxy;
+            if (det == 0.0f) ok = false;
+            else {
+                const float ox = -(Dyy * Dx - Dxy * Dy) / det, oy = -(Dxx * Dy - Dxy * Dx) / det;
+                if (!(fabsf(ox) <= 1.0f && fabsf(oy) <= 1.0f)) ok = false;
+            }
+            if (ok) out = v;
+        }
+    }
+    cand[((size_t)f * NLEV + lv) * n + (size_t)y * w + x] = out;
+}
+
+// ---- top-K selection: 2-pass radix select on the float bit patterns ---------------------------------
+// hist: [F][65536]; sel: [F][4] = {prefix, remaining, total, threshold_bits}
+template <int PASS>
+__global__ __launch_bounds__(256) void k_ov_sel_hist(const float *__restrict__ cand, size_t n4, uint32_t *__restrict__ hist,
+                                                    const uint32_t *__restrict__ sel)
+{
+    const int f = blockIdx.y;
+    const float *c = cand + (size_t)f * n4;
+    const uint32_t prefix = PASS == 1 ? sel[(size_t)f * 4] : 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const uint32_t b = __float_as_uint(c[i]);
+        if (b == 0) continue;
+        if (PASS == 1 && (b >> 16) != prefix) continue;
+        atomicAdd(&hist[(size_t)f * 65536 + (PASS == 0 ? (b >> 16) : (b & 0xffffu))], 1u);
+    }
+}
+
+// one block per frame: walk the 65536 bins from the top until `remaining` candidates are covered
+template <int PASS>
+__global__ __launch_bounds__(256) void k_ov_sel_pick(const uint32_t *__restrict__ hist, uint32_t *__restrict__ sel)
+{
+    __shared__ uint32_t s_sum[256];
+    __shared__ uint32_t s_scratch[8];
+    const int f = blockIdx.x, t = threadIdx.x;
+    const uint32_t *hh = hist + (size_t)f * 65536;
+    // thread t owns bins [65535 - 256 t - 255, 65535 - 256 t] (descending order across threads)
+    uint32_t mine = 0;
+    const int top = 65535 - 256 * t;
+    for (int b = top; b > top - 256; --b) mine += hh[b];
+    const uint32_t incl = block256_incl_scan_u32(mine, s_scratch);
+    s_sum[t] = incl;
+    __syncthreads();
+    uint32_t *s = sel + (size_t)f * 4;
+    const uint32_t total = s_sum[255];
+    uint32_t remaining = PASS == 0 ? (uint32_t)MAXKP : s[1];
+    if (PASS == 0 && t == 0) s[2] = total;
+    if (PASS == 0 && total <= (uint32_t)MAXKP) {
+        if (t == 0) { s[0] = 0; s[1] = 0; s[3] = 1u; }      // accept every candidate (bits >= 1)
+        return;
+    }
+    if (PASS == 1 && s[3] == 1u && s[2] <= (uint32_t)MAXKP) return;
+    const uint32_t before = incl - mine;
+    if (before < remaining && incl >= remaining) {
+        // the K-th strongest lies in this thread's 256 bins
+        uint32_t acc = before;
+        int b = top;
+        for (; b > top - 256; --b) {
+            if (acc + hh[b] >= remaining) break;
+            acc += hh[b];
+        }
+        if (PASS == 0) { s[0] = (uint32_t)b; s[1] = remaining - acc; }
+        else { s[3] = (s[0] << 16) | (uint32_t)b; }
+    }
+}
+
+// ---- ordered compaction + sub-pixel refinement ---------------------------------------------------------
+constexpr int CMP_CHUNK = 1024;
+__global__ __launch_bounds__(256) void k_ov_count(const float *__restrict__ cand, size_t n4, const uint32_t *__restrict__ sel,
+                                                 uint32_t *__restrict__ counts, int nchunks)
+{
+    __shared__ uint32_t scratch[8];
+    const int f = blockIdx.y, ch = blockIdx.x;
+    const uint32_t thr = sel[(size_t)f * 4 + 3];
+    const float *c = cand + (size_t)f * n4;
+    uint32_t m = 0;
+    for (int k = 0; k < CMP_CHUNK / 256; ++k) {
+        const size_t i = (size_t)ch * CMP_CHUNK + (size_t)k * 256 + threadIdx.x;
+        if (i < n4) {
+            const uint32_t b = __float_as_uint(c[i]);
+            m += (b != 0 && b >= thr) ? 1u : 0u;
+        }
+    }
+    const uint32_t tot = block256_sum_u32(m, scratch);
+    if (threadIdx.x == 0) counts[(size_t)f * nchunks + ch] = tot;
+}
+
+__global__ __launch_bounds__(256) void k_ov_scan_chunks(uint32_t *__restrict__ counts, int nchunks, int32_t *__restrict__ nkp)
+{
+    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t carry;
+    const int f = blockIdx.x;
+    uint32_t *c = counts + (size_t)f * nchunks;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nchunks; base += 256) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nchunks ? c[i] : 0u;
+        const uint32_t incl = block256_incl_scan_u32(v, scratch);
+        const uint32_t off = carry;
+        if (i < nchunks) c[i] = off + incl - v;       // exclusive offset
+        __syncthreads();
+        if (threadIdx.x == 255) carry = off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) nkp[f] = (int32_t)min(carry, (uint32_t)MAXKP);
+}
+
+__global__ __launch_bounds__(256) void k_ov_compact(const float *__restrict__ cand, const float *__restrict__ Ldet, int h, int w,
+                                                   const uint32_t *__restrict__ sel, const uint32_t *__restrict__ offsets,
+                                                   int nchunks, Keypoint *__restrict__ kps)
+{
+    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t s_base;
+    const int f = blockIdx.y, ch = blockIdx.x;
+    const size_t n = (size_t)h * w, n4 = n * NLEV;
+    const uint32_t thr = sel[(size_t)f * 4 + 3];
+    const float *c = cand + (size_t)f * n4;
+    if (threadIdx.x == 0) s_base = offsets[(size_t)f * nchunks + ch];
+    __syncthreads();
+    for (int k = 0; k < CMP_CHUNK / 256; ++k) {
+        const size_t i = (size_t)ch * CMP_CHUNK + (size_t)k * 256 + threadIdx.x;
+        uint32_t flag = 0;
+        float v = 0.0f;
+        if (i < n4) {
+            v = c[i];
+            const uint32_t b = __float_as_uint(v);
+            flag = (b != 0 && b >= thr) ? 1u : 0u;
+        }
+        const uint32_t incl = block256_incl_scan_u32(flag, scratch);
+        const uint32_t base = s_base;
+        const uint32_t pos = base + incl - flag;
+        if (flag && pos < (uint32_t)MAXKP) {
+            const int lv = (int)(i / n);
+            const size_t r = i - (size_t)lv * n;
+            const int y = (int)(r / w), x = (int)(r - (size_t)y * w);
+            const float *D = Ldet + ((size_t)f * NLEV + lv) * n;
+            const float vxp = D[(size_t)y * w + x + 1], vxm = D[(size_t)y * w + x - 1];
+            const float vyp = D[(size_t)(y + 1) * w + x], vym = D[(size_t)(y - 1) * w + x];
+            const float Dx = 0.5f * (vxp - vxm), Dy = 0.5f * (vyp - vym);
+            const float Dxx = (vxp + vxm) - 2.0f * v, Dyy = (vyp + vym) - 2.0f * v;
+            const float Dxy = 0.25f * (D[(size_t)(y + 1) * w + x + 1] + D[(size_t)(y - 1) * w + x - 1]) -
+                              0.25f * (D[(size_t)(y + 1) * w + x - 1] + D[(size_t)(y - 1) * w + x + 1]);
+            const float det = Dxx * Dyy - Dxy * Dxy;
+            const float ox = -(Dyy * Dx - Dxy * Dy) / det, oy = -(Dxx * Dy - Dxy * Dx) / det;
+            Keypoint kp;
+            kp.x = (float)x + ox; kp.y = (float)y + oy; kp.response = v;
+            kp.level = lv; kp.xi = x; kp.yi = y; kp.pad0 = 0; kp.pad1 = 0;
+            kps[(size_t)f * MAXKP + pos] = kp;
+        }
+        __syncthreads();
+        if (threadIdx.x == 255) s_base = base + incl;
+        __syncthreads();
+    }
+}
+
+// ---- upright M-LDB: one wave per keypoint ---------------------------------------------------------------
+// lanes 0..28 each own one cell (4 + 9 + 16) and sum its samples sequentially (fixed order = oracle's);
+// then the 486 comparisons are spread over the 64 lanes.
+__global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt, const float *__restrict__ Lx, const float *__restrict__ Ly,
+                                                   int h, int w, const Keypoint *__restrict__ kps, const int32_t *__restrict__ nkp,
+                                                   uint8_t *__restrict__ desc, int8_t *__restrict__ bits, int32_t *__restrict__ pop)
+{
+    __shared__ float s_val[29][3];
+    __shared__ uint32_t s_words[16];
+    const int f = blockIdx.y, q = blockIdx.x, lane = threadIdx.x;
+    const int n = nkp[f];
+    uint8_t *d = desc + ((size_t)f * MAXKP + q) * DESC_BYTES;
+    int8_t *bq = bits + ((size_t)f * MAXKP + q) * DESC_K;
+    if (q >= n) {
+        // unused slots: all-zero descriptor (keeps the MFMA operand defined)
+        if (lane < 16) reinterpret_cast<uint32_t *>(d)[lane] = 0;
+        for (int i = lane; i < DESC_K / 4; i += 64) reinterpret_cast<uint32_t *>(bq)[i] = 0;
+        if (lane == 0) pop[(size_t)f * MAXKP + q] = 0;
+        return;
+    }
+    const Keypoint kp = kps[(size_t)f * MAXKP + q];
+    const size_t npx = (size_t)h * w;
+    const float *T = Lt + ((size_t)f * NLEV + kp.level) * npx;
+    const float *X = Lx + ((size_t)f * NLEV + kp.level) * npx;
+    const float *Y = Ly + ((size_t)f * NLEV + kp.level) * npx;
+    const float sc = (float)D_SSIZE[kp.level];
+    if (lane < 16) s_words[lane] = 0;
+    if (lane < 29) {
+        int z, ci;
+        if (lane < 4) { z = 0; ci = lane; } else if (lane < 13) { z = 1; ci = lane - 4; } else { z = 2; ci = lane - 13; }
+        const int st = z == 0 ? 10 : (z == 1 ? 7 : 5), nc = z + 2;
+        const int i0 = -10 + (ci / nc) * st, j0 = -10 + (ci % nc) * st;       // i (x) major, j (y) minor
+        float di = 0.0f, dx = 0.0f, dy = 0.0f;
+        int ns = 0;
+        for (int kk = i0; kk < i0 + st; ++kk)
+            for (int l = j0; l < j0 + st; ++l) {
+                const float sy = kp.y + (float)l * sc, sx = kp.x + (float)kk * sc;
+                const int y1 = min(max((int)floorf(sy + 0.5f), 0), h - 1);
+                const int x1 = min(max((int)floorf(sx + 0.5f), 0), w - 1);
+                di = di + T[(size_t)y1 * w + x1];
+                dx = dx + X[(size_t)y1 * w + x1];
+                dy = dy + Y[(size_t)y1 * w + x1];
+                ns++;
+            }
+        s_val[lane][0] = di / (float)ns; s_val[lane][1] = dx / (float)ns; s_val[lane][2] = dy / (float)ns;
+    }
+    __syncthreads();
+    // bit b (0..485): (z, channel, pair); enumerate in the oracle's order
+    for (int b = lane; b < 486; b += 64) {
+        int z, rem, ncell, base;
+        if (b < 18) { z = 0; rem = b; ncell = 4; base = 0; }
+        else if (b < 126) { z = 1; rem = b - 18; ncell = 9; base = 4; }
+        else { z = 2; rem = b - 126; ncell = 16; base = 13; }
+        (void)z;
+        const int npairs = ncell * (ncell - 1) / 2;
+        const int c = rem / npairs;
+        int p = rem - c * npairs;
+        int a = 0;
+        while (p >= ncell - 1 - a) { p -= ncell - 1 - a; a++; }
+        const int bb = a + 1 + p;
+        const int bit = s_val[base + a][c] > s_val[base + bb][c] ? 1 : 0;
+        bq[b] = (int8_t)bit;
+        if (bit) atomicOr(&s_words[b >> 5], 1u << (b & 31));
+    }
+    for (int b = 486 + lane; b < DESC_K; b += 64) bq[b] = 0;
+    __syncthreads();
+    if (lane < 16) reinterpret_cast<uint32_t *>(d)[lane] = s_words[lane];
+    if (lane == 0) {
+        int pc = 0;
+        for (int i = 0; i < 16; ++i) pc += __popc(s_words[i]);
+        pop[(size_t)f * MAXKP + q] = pc;
+    }
+}
+
+// ---- brute-force Hamming kNN(2): dense q x t dot products on i8 MFMA -------------------------------------
+// popcount(a xor b) = |a| + |b| - 2 a.b with a, b in {0,1}^512 held as bytes.
+// Block = 4 waves = 64 queries; train descriptors staged through LDS 64 at a time (row stride 528 B:
+// the 16 lanes of a ds_read_b128 group then fall on 16 different 16-byte slots).
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr int MT_ROW = DESC_K + 16;
+
+struct Top2 {
+    int d0, i0, d1, i1;
+};
+__device__ __forceinline__ bool lessdi(int da, int ia, int db, int ib) { return da < db || (da == db && ia < ib); }
+__device__ __forceinline__ void top2_insert(Top2 &t, int d, int i)
+{
+    if (lessdi(d, i, t.d0, t.i0)) { t.d1 = t.d0; t.i1 = t.i0; t.d0 = d; t.i0 = i; }
+    else if (lessdi(d, i, t.d1, t.i1)) { t.d1 = d; t.i1 = i; }
+}
+
+__global__ __launch_bounds__(256) void k_ov_match(const int8_t *__restrict__ qbits, const int32_t *__restrict__ qpop,
+                                                 const int32_t *__restrict__ qn, const int8_t *__restrict__ tbits,
+                                                 const int32_t *__restrict__ tpop, const int32_t *__restrict__ tn,
+                                                 const int32_t *__restrict__ pair_q, const int32_t *__restrict__ pair_t,
+                                                 int32_t *__restrict__ out_idx /*[P][MAXKP][2]*/, int32_t *__restrict__ out_dist)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t s_t[];      // [64][MT_ROW]
+    const int p = blockIdx.y;
+    const int fq = pair_q[p], ft = pair_t[p];
+    const int nq = qn[fq], nt = tn[ft];
+    const int q0 = blockIdx.x * 64;
+    if (q0 >= nq) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 15, kb = lane >> 4;
+    const int8_t *Q = qbits + (size_t)fq * MAXKP * DESC_K;
+    const int8_t *T = tbits + (size_t)ft * MAXKP * DESC_K;
+    // A fragments: query (q0 + wave*16 + row), bytes [64*ks + 16*kb, +16)
+    v4i a[8];
+    const int qrow = q0 + wave * 16 + row;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+        a[ks] = *reinterpret_cast<const v4i *>(Q + (size_t)qrow * DESC_K + ks * 64 + kb * 16);
+    // this lane's 4 accumulator rows: q = q0 + wave*16 + kb*4 + r
+    int cq[4];
+    Top2 best[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        cq[r] = qpop[(size_t)fq * MAXKP + q0 + wave * 16 + kb * 4 + r];
+        best[r] = {1 << 30, 1 << 30, 1 << 30, 1 << 30};
+    }
+    for (int t0 = 0; t0 < nt; t0 += 64) {
+        __syncthreads();
+        // stage 64 train descriptors (32 KB): 2048 x 16-byte pieces, 8 per thread
+        for (int i = threadIdx.x; i < 64 * (DESC_K / 16); i += 256) {
+            const int tr = i >> 5, piece = i & 31;
+            const v4i v = *reinterpret_cast<const v4i *>(T + (size_t)(t0 + tr) * DESC_K + piece * 16);
+            *reinterpret_cast<v4i *>(s_t + (size_t)tr * MT_ROW + piece * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            v4i acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const v4i b = *reinterpret_cast<const v4i *>(s_t + (size_t)(tt * 16 + row) * MT_ROW + ks * 64 + kb * 16);
+                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks], b, acc, 0, 0, 0);
+            }
+            const int t = t0 + tt * 16 + row;           // C/D: col = lane & 15, row = (lane >> 4) * 4 + reg
+            if (t < nt) {
+                const int ct = tpop[(size_t)ft * MAXKP + t];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) top2_insert(best[r], cq[r] + ct - 2 * acc[r], t);
+            }
+        }
+    }
+    // merge the 16 lanes (lane & 15) that hold different columns of the same query rows
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int od0 = __shfl_xor(best[r].d0, d, 64), oi0 = __shfl_xor(best[r].i0, d, 64);
+            const int od1 = __shfl_xor(best[r].d1, d, 64), oi1 = __shfl_xor(best[r].i1, d, 64);
+            top2_insert(best[r], od0, oi0);
+            top2_insert(best[r], od1, oi1);
+        }
+        const int q = q0 + wave * 16 + kb * 4 + r;
+        if (row == 0 && q < nq) {
+            const size_t o = ((size_t)p * MAXKP + q) * 2;
+            const bool h0 = best[r].i0 < (1 << 30), h1 = best[r].i1 < (1 << 30);
+            out_idx[o] = h0 ? best[r].i0 : -1; out_idx[o + 1] = h1 ? best[r].i1 : -1;
+            out_dist[o] = h0 ? best[r].d0 : -1; out_dist[o + 1] = h1 ? best[r].d1 : -1;
+        }
+    }
+}
+
+// ---- ratio test + RANSAC homography + overlapArea, one block per pair ---------------------------------------
+__device__ __forceinline__ uint32_t hash32(uint32_t a)
+{
+    a ^= a >> 16; a *= 0x7feb352du; a ^= a >> 15; a *= 0x846ca68bu; a ^= a >> 16;
+    return a;
+}
+
+__device__ bool solve8(double A[8][9])
+{
+    for (int c = 0; c < 8; ++c) {
+        int p = c;
+        for (int r = c + 1; r < 8; ++r) if (fabs(A[r][c]) > fabs(A[p][c])) p = r;
+        if (!(fabs(A[p][c]) > 1e-12)) return false;
+        if (p != c) for (int k = 0; k < 9; ++k) { const double t = A[c][k]; A[c][k] = A[p][k]; A[p][k] = t; }
+        for (int r = c + 1; r < 8; ++r) {
+            const double f = A[r][c] / A[c][c];
+            for (int k = c; k < 9; ++k) A[r][k] = A[r][k] - f * A[c][k];
+        }
+    }
+    for (int r = 7; r >= 0; --r) {
+        double s = A[r][8];
+        for (int k = r + 1; k < 8; ++k) s = s - A[r][k] * A[k][8];
+        A[r][8] = s / A[r][r];
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool is_inlier(const double *H, double x, double y, double X, double Y)
+{
+    const double wv = H[6] * x + H[7] * y + H[8];
+    const double px = (H[0] * x + H[1] * y + H[2]) / wv, py = (H[3] * x + H[4] * y + H[5]) / wv;
+    const double ex = px - X, ey = py - Y;
+    return (ex * ex + ey * ey) <= 9.0;
+}
+
+__device__ bool clip_line(long long W, long long Hh, long long &x1, long long &y1, long long &x2, long long &y2)
+{
+    const long long right = W - 1, bottom = Hh - 1;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+                x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+                x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+constexpr int MASK_WORDS = TW / 32;     // 20 words per row
+
+__device__ void draw_line(uint32_t *mask, long long x1, long long y1, long long x2, long long y2)
+{
+    if (!clip_line(TW, TH, x1, y1, x2, y2)) return;
+    if (x2 < x1) { long long t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }
+    int dx = (int)(x2 - x1), dy = (int)(y2 - y1);
+    const int sx = dx < 0 ? -1 : 1, sy = dy < 0 ? -1 : 1;
+    dx = dx < 0 ? -dx : dx; dy = dy < 0 ? -dy : dy;
+    int x = (int)x1, y = (int)y1;
+    if (dy > dx) {
+        int err = dy - (dx + dx);
+        for (int i = 0; i <= dy; ++i) {
+            mask[y * MASK_WORDS + (x >> 5)] |= 1u << (x & 31);
+            const int m = err < 0;
+            err += -(dx + dx) + (m ? dy + dy : 0);
+            y += sy;
+            if (m) x += sx;
+        }
+    } else {
+        int err = dx - (dy + dy);
+        for (int i = 0; i <= dx; ++i) {
+            mask[y * MASK_WORDS + (x >> 5)] |= 1u << (x & 31);
+            const int m = err < 0;
+            err += -(dy + dy) + (m ? dx + dx : 0);
+            x += sx;
+            if (m) y += sy;
+        }
+    }
+}
+
+// scanline part of cv::fillConvexPoly (shift 0): per-row span ends into span[y] = (xx1, xx2) or (1, 0)
+__device__ void fill_spans(const long long vx[4], const long long vy[4], short2 *span)
+{
+    const int XY_SHIFT = 16;
+    const long long XY_ONE = 1 << XY_SHIFT;
+    const int npts = 4;
+    struct { int idx, di; long long x, dx; int ye; } edge[2];
+    const int delta1 = (int)(XY_ONE >> 1), delta2 = (int)(XY_ONE >> 1);
+    int imin = 0, edges = npts;
+    long long xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
+    for (int i = 0; i < npts; ++i) {
+        if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
+        if (vy[i] > ymax) ymax = vy[i];
+        if (vx[i] > xmax) xmax = vx[i];
+        if (vx[i] < xmin) xmin = vx[i];
+    }
+    if ((int)xmax < 0 || (int)ymax < 0 || (int)xmin >= TW || (int)ymin >= TH) return;
+    if (ymax > TH - 1) ymax = TH - 1;
+    int y = (int)ymin;
+    edge[0].idx = edge[1].idx = imin;
+    edge[0].ye = edge[1].ye = y;
+    edge[0].di = 1; edge[1].di = npts - 1;
+    edge[0].x = edge[1].x = -XY_ONE;
+    edge[0].dx = edge[1].dx = 0;
+    do {
+        for (int i = 0; i < 2; ++i) {
+            if (y >= edge[i].ye) {
+                int idx0 = edge[i].idx;
+                const int di = edge[i].di;
+                int idx = idx0 + di;
+                if (idx >= npts) idx -= npts;
+                for (; edges-- > 0;) {
+                    const int ty = (int)vy[idx];
+                    if (ty > y) {
+                        const long long xs = vx[idx0] << XY_SHIFT, xe = vx[idx] << XY_SHIFT;
+                        edge[i].ye = ty;
+                        edge[i].dx = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
+                        edge[i].x = xs;
+                        edge[i].idx = idx;
+                        break;
+                    }
+                    idx0 = idx;
+                    idx += di;
+                    if (idx >= npts) idx -= npts;
+                }
+            }
+        }
+        if (edges < 0) break;
+        if (y >= 0) {
+            int left = 0, right = 1;
+            if (edge[0].x > edge[1].x) { left = 1; right = 0; }
+            int xx1 = (int)((edge[left].x + delta1) >> XY_SHIFT);
+            int xx2 = (int)((edge[right].x + delta2) >> XY_SHIFT);
+            if (xx2 >= 0 && xx1 < TW) {
+                if (xx1 < 0) xx1 = 0;
+                if (xx2 >= TW) xx2 = TW - 1;
+                span[y] = make_short2((short)xx1, (short)xx2);
+            }
+        }
+        edge[0].x += edge[0].dx;
+        edge[1].x += edge[1].dx;
+    } while (++y <= (int)ymax);
+}
+
+// overlapArea(H), videostrip.cpp:291-319.  Must be called by the whole 256-thread block.
+__device__ float overlap_area_block(const double *H, int videoW, int videoH, uint32_t *s_mask /*[TH*MASK_WORDS]*/,
+                                    short2 *s_span /*[TH]*/, uint32_t *scratch, int *ov_out)
+{
+    __shared__ float s_f[8];
+    for (int i = threadIdx.x; i < TH * MASK_WORDS; i += 256) s_mask[i] = 0;
+    for (int i = threadIdx.x; i < TH; i += 256) s_span[i] = make_short2(1, 0);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float px[4] = {0, (float)TW, (float)TW, 0}, py[4] = {0, 0, (float)TH, (float)TH};
+        long long vx[4], vy[4];
+        for (int i = 0; i < 4; ++i) {
+            const double x = px[i], y = py[i];
+            double wv = x * H[6] + y * H[7] + H[8];
+            float fx = 0.0f, fy = 0.0f;
+            if (fabs(wv) > 2.220446049250313e-16) {
+                wv = 1.0 / wv;
+                fx = (float)((x * H[0] + y * H[1] + H[2]) * wv);
+                fy = (float)((x * H[3] + y * H[4] + H[5]) * wv);
+            }
+            s_f[i] = fx; s_f[4 + i] = fy;
+            vx[i] = (long long)__float2int_rn(fx);
+            vy[i] = (long long)__float2int_rn(fy);
+        }
+        for (int i = 0; i < 4; ++i) {
+            const int p = (i + 3) % 4;
+            draw_line(s_mask, vx[p], vy[p], vx[i], vy[i]);
+        }
+        fill_spans(vx, vy, s_span);
+    }
+    __syncthreads();
+    uint32_t cnt = 0;
+    for (int i = threadIdx.x; i < TH * MASK_WORDS; i += 256) {
+        const int y = i / MASK_WORDS, wd = i - y * MASK_WORDS;
+        uint32_t m = s_mask[i];
+        const short2 sp = s_span[y];
+        const int lo = max((int)sp.x, wd * 32), hi = min((int)sp.y, wd * 32 + 31);
+        if (lo <= hi) {
+            const int nb = hi - lo + 1;
+            const uint32_t bitsm = nb == 32 ? 0xffffffffu : (((1u << nb) - 1u) << (lo & 31));
+            m |= bitsm;
+        }
+        cnt += __popc(m);
+    }
+    const uint32_t ov = block256_sum_u32(cnt, scratch);
+    if (ov_out) *ov_out = (int)ov;
+    double a00 = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int p = (i + 3) % 4;
+        a00 += (double)s_f[p] * s_f[4 + i] - (double)s_f[4 + p] * s_f[i];
+    }
+    const float area1 = (float)(videoW * videoH), area2 = (float)fabs(a00 * 0.5), cur = (float)ov;
+    return cur / (area1 + area2 - cur);
+}
+
+constexpr int NSUM = 44;
+
+__global__ __launch_bounds__(256) void k_ov_geometry(const Keypoint *__restrict__ qkp, const Keypoint *__restrict__ tkp,
+                                                    const int32_t *__restrict__ qn, const int32_t *__restrict__ tn,
+                                                    const int32_t *__restrict__ pair_q, const int32_t *__restrict__ pair_t,
+                                                    const int32_t *__restrict__ m_idx, const int32_t *__restrict__ m_dist,
+                                                    int w, int h, int videoW, int videoH, uint32_t seed,
+                                                    float *__restrict__ ratio, int32_t *__restrict__ info /*[P][8]*/,
+                                                    double *__restrict__ Hout /*[P][9]*/)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_raw[];
+    // carve: good points 4 x MAXKP floats (32 KB) | inlier flags MAXKP (2 KB) | mask (38.4 KB) | spans (1.9 KB)
+    float *s_ox = reinterpret_cast<float *>(s_raw), *s_oy = s_ox + MAXKP, *s_sx = s_oy + MAXKP, *s_sy = s_sx + MAXKP;
+    uint8_t *s_inl = reinterpret_cast<uint8_t *>(s_sy + MAXKP);
+    uint32_t *s_mask = reinterpret_cast<uint32_t *>(s_inl + MAXKP);
+    short2 *s_span = reinterpret_cast<short2 *>(s_mask + TH * MASK_WORDS);
+    __shared__ uint32_t scratch[16];
+    __shared__ int s_best_cnt[256], s_best_it[256];
+    __shared__ double s_H[9];
+    __shared__ double s_g[4][NSUM];
+    __shared__ int s_ng;
+
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int fq = pair_q[p], ft = pair_t[p];
+    const int nq = qn[fq], nt = tn[ft];
+    const Keypoint *KQ = qkp + (size_t)fq * MAXKP, *KT = tkp + (size_t)ft * MAXKP;
+    const int32_t *mi = m_idx + (size_t)p * MAXKP * 2, *md = m_dist + (size_t)p * MAXKP * 2;
+    int32_t *inf = info + (size_t)p * 8;
+
+    // ratio test (videostrip.cpp:233-242; last query skipped, B-12), order-preserving compaction
+    if (tid == 0) s_ng = 0;
+    __syncthreads();
+    const int limit = (nt >= 2 && nq >= 1) ? nq - 1 : 0;
+    for (int base = 0; base < limit; base += 256) {
+        const int k = base + tid;
+        uint32_t good = 0;
+        if (k < limit) good = ((double)md[k * 2] < 0.8 * (double)md[k * 2 + 1]) ? 1u : 0u;
+        const uint32_t incl = block256_incl_scan_u32(good, scratch);
+        const int off = s_ng;
+        if (good) {
+            const int pos = off + (int)(incl - 1);
+            const Keypoint a = KQ[k], b = KT[mi[k * 2]];
+            s_ox[pos] = a.x; s_oy[pos] = a.y; s_sx[pos] = b.x; s_sy[pos] = b.y;
+        }
+        __syncthreads();
+        if (tid == 255) s_ng = off + (int)incl;
+        __syncthreads();
+    }
+    const int ng = s_ng;
+    if (tid == 0) { inf[0] = nq; inf[1] = nt; inf[2] = ng; inf[3] = 0; inf[4] = 0; }
+    if (ng < 4) {                                    // "Not enough good matches" -> -2.0 (videostrip.cpp:252-256)
+        if (tid == 0) ratio[p] = -2.0f;
+        return;
+    }
+    // 512 hypotheses, 2 per thread
+    int my_cnt = 0, my_it = 0x7fffffff;
+    for (int rep = 0; rep < RANSAC_ITERS / 256; ++rep) {
+        const int it = rep * 256 + tid;
+        int pick[4];
+        for (int j = 0; j < 4; ++j) {
+            uint32_t attempt = 0;
+            for (;;) {
+                const uint32_t r = hash32(seed ^ hash32((uint32_t)(it * 4 + j + 1) + attempt * 0x9e3779b9u));
+                const int c = (int)(r % (uint32_t)ng);
+                bool dup = false;
+                for (int m = 0; m < j; ++m) dup = dup || (pick[m] == c);
+                if (!dup || attempt >= 16) { pick[j] = c; break; }
+                attempt++;
+            }
+        }
+        double A[8][9];
+        for (int j = 0; j < 4; ++j) {
+            const double x = s_ox[pick[j]], y = s_oy[pick[j]], X = s_sx[pick[j]], Y = s_sy[pick[j]];
+            double *r0 = A[2 * j], *r1 = A[2 * j + 1];
+            r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -x * X; r0[7] = -y * X; r0[8] = X;
+            r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -x * Y; r1[7] = -y * Y; r1[8] = Y;
+        }
+        if (!solve8(A)) continue;
+        double Hc[9];
+        for (int k = 0; k < 8; ++k) Hc[k] = A[k][8];
+        Hc[8] = 1.0;
+        int cnt = 0;
+        for (int i = 0; i < ng; ++i) cnt += is_inlier(Hc, s_ox[i], s_oy[i], s_sx[i], s_sy[i]) ? 1 : 0;
+        if (cnt > my_cnt) { my_cnt = cnt; my_it = it; }      // it increases: keeps the first maximum
+    }
+    s_best_cnt[tid] = my_cnt; s_best_it[tid] = my_it;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (tid < s) {
+            const int oc = s_best_cnt[tid + s], oi = s_best_it[tid + s];
+            if (oc > s_best_cnt[tid] || (oc == s_best_cnt[tid] && oi < s_best_it[tid])) { s_best_cnt[tid] = oc; s_best_it[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    const int best = s_best_cnt[0], best_it = s_best_it[0];
+    if (best < 4) {                                   // H.empty() -> -2.0 (videostrip.cpp:272)
+        if (tid == 0) ratio[p] = -2.0f;
+        return;
+    }
+    if (tid == 0) {
+        // rebuild the winning hypothesis
+        int pick[4];
+        for (int j = 0; j < 4; ++j) {
+            uint32_t attempt = 0;
+            for (;;) {
+                const uint32_t r = hash32(seed ^ hash32((uint32_t)(best_it * 4 + j + 1) + attempt * 0x9e3779b9u));
+                const int c = (int)(r % (uint32_t)ng);
+                bool dup = false;
+                for (int m = 0; m < j; ++m) dup = dup || (pick[m] == c);
+                if (!dup || attempt >= 16) { pick[j] = c; break; }
+                attempt++;
+            }
+        }
+        double A[8][9];
+        for (int j = 0; j < 4; ++j) {
+            const double x = s_ox[pick[j]], y = s_oy[pick[j]], X = s_sx[pick[j]], Y = s_sy[pick[j]];
+            double *r0 = A[2 * j], *r1 = A[2 * j + 1];
+            r0[0] = x; r0[1] = y; r0[2] = 1; r0[3] = 0; r0[4] = 0; r0[5] = 0; r0[6] = -x * X; r0[7] = -y * X; r0[8] = X;
+            r1[0] = 0; r1[1] = 0; r1[2] = 0; r1[3] = x; r1[4] = y; r1[5] = 1; r1[6] = -x * Y; r1[7] = -y * Y; r1[8] = Y;
+        }
+        solve8(A);
+        for (int k = 0; k < 8; ++k) s_H[k] = A[k][8];
+        s_H[8] = 1.0;
+        inf[3] = best;
+    }
+    __syncthreads();
+    for (int i = tid; i < ng; i += 256) s_inl[i] = is_inlier(s_H, s_ox[i], s_oy[i], s_sx[i], s_sy[i]) ? 1 : 0;
+    __syncthreads();
+    // least-squares refit in fixed-normalised coordinates; summation order = the oracle's
+    const double cx = 0.5 * (double)w, cy = 0.5 * (double)h, sN = 0.5 * (double)w;
+    double part[NSUM];
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) part[k] = 0.0;
+    for (int i = tid; i < ng; i += 256) {
+        if (!s_inl[i]) continue;
+        const double x = ((double)s_ox[i] - cx) / sN, y = ((double)s_oy[i] - cy) / sN;
+        const double X = ((double)s_sx[i] - cx) / sN, Y = ((double)s_sy[i] - cy) / sN;
+        const double a[8] = {x, y, 1, 0, 0, 0, -x * X, -y * X}, b[8] = {0, 0, 0, x, y, 1, -x * Y, -y * Y};
+        int k = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int c = r; c < 8; ++c) { part[k] = part[k] + (a[r] * a[c] + b[r] * b[c]); k++; }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { part[k] = part[k] + (a[r] * X + b[r] * Y); k++; }
+    }
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) {
+        double v = part[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v = v + __shfl_xor(v, d, 64);
+        if ((tid & 63) == 0) s_g[tid >> 6][k] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double A[8][9];
+        int k = 0;
+        for (int r = 0; r < 8; ++r)
+            for (int c = r; c < 8; ++c) {
+                const double t = ((s_g[0][k] + s_g[1][k]) + s_g[2][k]) + s_g[3][k];
+                A[r][c] = t; A[c][r] = t; k++;
+            }
+        for (int r = 0; r < 8; ++r) { A[r][8] = ((s_g[0][k] + s_g[1][k]) + s_g[2][k]) + s_g[3][k]; k++; }
+        int ok = solve8(A) ? 1 : 0;
+        if (ok) {
+            const double hn[9] = {A[0][8], A[1][8], A[2][8], A[3][8], A[4][8], A[5][8], A[6][8], A[7][8], 1.0};
+            double M[9], R[9];
+            for (int r = 0; r < 3; ++r) {
+                M[r * 3 + 0] = hn[r * 3 + 0] / sN;
+                M[r * 3 + 1] = hn[r * 3 + 1] / sN;
+                M[r * 3 + 2] = (hn[r * 3 + 2] - hn[r * 3 + 0] * (cx / sN)) - hn[r * 3 + 1] * (cy / sN);
+            }
+            for (int c = 0; c < 3; ++c) {
+                R[0 * 3 + c] = sN * M[0 * 3 + c] + cx * M[2 * 3 + c];
+                R[1 * 3 + c] = sN * M[1 * 3 + c] + cy * M[2 * 3 + c];
+                R[2 * 3 + c] = M[2 * 3 + c];
+            }
+            if (R[8] == 0.0 || R[8] != R[8]) ok = 0;
+            else for (int i = 0; i < 9; ++i) s_H[i] = R[i] / R[8];
+        }
+        (void)ok;
+        if (Hout) for (int i = 0; i < 9; ++i) Hout[(size_t)p * 9 + i] = s_H[i];
+    }
+    __syncthreads();
+    int ov = 0;
+    const float r = overlap_area_block(s_H, videoW, videoH, s_mask, s_span, scratch, &ov);
+    if (tid == 0) { ratio[p] = r; inf[4] = ov; }
+}
+
+// standalone overlapArea on a list of homographies
+__global__ __launch_bounds__(256) void k_ov_area_only(const double *__restrict__ Hs, int videoW, int videoH, float *__restrict__ ratio,
+                                                     int32_t *__restrict__ ovc)
+{
+    __shared__ uint32_t s_mask[TH * MASK_WORDS];
+    __shared__ short2 s_span[TH];
+    __shared__ uint32_t scratch[16];
+    __shared__ double s_H[9];
+    if (threadIdx.x < 9) s_H[threadIdx.x] = Hs[(size_t)blockIdx.x * 9 + threadIdx.x];
+    __syncthreads();
+    int ov = 0;
+    const float r = overlap_area_block(s_H, videoW, videoH, s_mask, s_span, scratch, &ov);
+    if (threadIdx.x == 0) { ratio[blockIdx.x] = r; if (ovc) ovc[blockIdx.x] = ov; }
+}
+
+// ---- V5 calcBlur: gray -> Laplacian (aperture 3, saturated to u8) -> population stddev ---------------------------
+__global__ __launch_bounds__(256) void k_ov_blur(const uint8_t *__restrict__ gray, int h, int w, double *__restrict__ part /*[F][nb][2]*/)
+{
+    __shared__ double scratch[8];
+    const int f = blockIdx.y;
+    const uint8_t *g = gray + (size_t)f * h * w;
+    const size_t n = (size_t)h * w;
+    double s = 0.0, s2 = 0.0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const int y = (int)(i / w), x = (int)(i - (size_t)y * w);
+        const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h), xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+        int v = 2 * (g[(size_t)ym * w + xm] + g[(size_t)ym * w + xp] + g[(size_t)yp * w + xm] + g[(size_t)yp * w + xp]) - 8 * g[(size_t)y * w + x];
+        v = min(max(v, 0), 255);
+        s += v; s2 += (double)v * v;
+    }
+    // integer-valued sums: exact in double, so the reduction order is immaterial
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s = wave_sum_f64(s); s2 = wave_sum_f64(s2);
+    if (lane == 0) { scratch[wave] = s; scratch[4 + wave] = s2; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double *o = part + ((size_t)f * gridDim.x + blockIdx.x) * 2;
+        o[0] = scratch[0] + scratch[1] + scratch[2] + scratch[3];
+        o[1] = scratch[4] + scratch[5] + scratch[6] + scratch[7];
+    }
+}
+
+__global__ void k_ov_blur_final(const double *__restrict__ part, int nb, double npix, float *__restrict__ out, int F)
+{
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    double s = 0, s2 = 0;
+    for (int k = 0; k < nb; ++k) { s += part[((size_t)f * nb + k) * 2]; s2 += part[((size_t)f * nb + k) * 2 + 1]; }
+    const double mean = s / npix;
+    const double var = s2 / npix - mean * mean;
+    out[f] = (float)sqrt(var < 0 ? 0 : var);
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+ConvK gauss_kernel(float sigma)
+{
+    ConvK K{};
+    int ks = (int)std::ceil(2.0 * (1.0 + ((double)sigma - 0.8) / 0.3));
+    if ((ks & 1) == 0) ks++;
+    const int r = ks / 2;
+    double sum = 0, tmp[32];
+    for (int i = 0; i < ks; ++i) { tmp[i] = std::exp(-((double)(i - r) * (i - r)) / (2.0 * (double)sigma * (double)sigma)); sum += tmp[i]; }
+    K.ks = ks;
+    for (int i = 0; i < ks; ++i) K.k[i] = (float)(tmp[i] / sum);
+    return K;
+}
+
+int fed_taus(float T, float *tau)
+{
+    const double tau_max = 0.25;
+    int n = (int)(std::ceil(std::sqrt(3.0 * (double)T / tau_max + 0.25) - 0.5 - 1.0e-8) + 0.5);
+    if (n < 1) n = 1;
+    const double scale = 3.0 * (double)T / (tau_max * (double)(n * (n + 1)));
+    const double c = 1.0 / (4.0 * (double)n + 2.0), d = scale * tau_max / 2.0;
+    for (int k = 0; k < n; ++k) {
+        const double hh = std::cos(3.14159265358979323846 * (2.0 * (double)k + 1.0) * c);
+        tau[k] = (float)(d / (hh * hh));
+    }
+    return n;
+}
+
+void resize_dims(int rows, int cols, int target_w, int *orows, int *ocols)
+{
+    const float f = (float)target_w / (float)cols;                 // hResizeFactor (main.cpp:242)
+    *ocols = (int)std::lrint((double)cols * (double)f);
+    *orows = (int)std::lrint((double)rows * (double)f);
+}
+
+struct ResizeTab {
+    std::vector<int> ofs;
+    std::vector<short> c0, c1;
+};
+
+void resize_tab(int ssize, int dsize, ResizeTab &t)
+{
+    t.ofs.resize(dsize); t.c0.resize(dsize); t.c1.resize(dsize);
+    const double scale = 1.0 / ((double)dsize / (double)ssize);
+    for (int d = 0; d < dsize; ++d) {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        int sx = (int)std::floor(fx);
+        fx -= (float)sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= ssize - 1) { fx = 0; sx = ssize - 1; }
+        t.ofs[d] = sx;
+        const long r0 = std::lrintf((1.0f - fx) * 2048.0f), r1 = std::lrintf(fx * 2048.0f);
+        t.c0[d] = (short)std::min<long>(r0, 32767);
+        t.c1[d] = (short)std::min<long>(r1, 32767);
+    }
+}
+
+// device table: [ofs int32 x d][c0 int16 x d][c1 int16 x d]
+const void *resize_table(uwip_ctx *ctx, int ssize, int dsize)
+{
+    char key[64];
+    snprintf(key, sizeof key, "resize:%d:%d", ssize, dsize);
+    const void *d = uwip_table_find(ctx, key, nullptr);
+    if (d) return d;
+    ResizeTab t;
+    resize_tab(ssize, dsize, t);
+    std::vector<uint8_t> buf((size_t)dsize * 8);
+    memcpy(buf.data(), t.ofs.data(), (size_t)dsize * 4);
+    memcpy(buf.data() + (size_t)dsize * 4, t.c0.data(), (size_t)dsize * 2);
+    memcpy(buf.data() + (size_t)dsize * 6, t.c1.data(), (size_t)dsize * 2);
+    return uwip_table_put(ctx, key, buf.data(), buf.size());
+}
+
+dim3 grid2d(int w, int h, int z) { return dim3(uwip_cdiv(w, 64), uwip_cdiv(h, 4), (unsigned)z); }
+
+struct OvWork {
+    uint8_t *gray;
+    float *L0, *tmp, *Lsm, *flow, *ping, *Lt, *Lx, *Ly, *Ldet, *cand, *kc;
+    uint32_t *hmax, *khist, *selhist, *sel, *counts;
+};
+
+int alloc_work(uwip_ctx *ctx, int F, int h, int w, OvWork *W)
+{
+    const size_t n = (size_t)h * w;
+    const int nchunks = (int)((n * NLEV + CMP_CHUNK - 1) / CMP_CHUNK);
+    W->gray = (uint8_t *)uwip_ws(ctx, "ov.gray", n * F);
+    W->L0 = (float *)uwip_ws(ctx, "ov.L0", n * F * 4);
+    W->tmp = (float *)uwip_ws(ctx, "ov.tmp", n * F * 4);
+    W->Lsm = (float *)uwip_ws(ctx, "ov.Lsm", n * F * 4);
+    W->flow = (float *)uwip_ws(ctx, "ov.flow", n * F * 4);
+    W->ping = (float *)uwip_ws(ctx, "ov.ping", n * F * 4);
+    W->Lt = (float *)uwip_ws(ctx, "ov.Lt", n * F * 4 * NLEV);
+    W->Lx = (float *)uwip_ws(ctx, "ov.Lx", n * F * 4 * NLEV);
+    W->Ly = (float *)uwip_ws(ctx, "ov.Ly", n * F * 4 * NLEV);
+    W->Ldet = (float *)uwip_ws(ctx, "ov.Ldet", n * F * 4 * NLEV);
+    W->cand = (float *)uwip_ws(ctx, "ov.cand", n * F * 4 * NLEV);
+    W->kc = (float *)uwip_ws(ctx, "ov.kc", sizeof(float) * F);
+    W->hmax = (uint32_t *)uwip_ws(ctx, "ov.hmax", sizeof(uint32_t) * F);
+    W->khist = (uint32_t *)uwip_ws(ctx, "ov.khist", sizeof(uint32_t) * 304 * F);
+    W->selhist = (uint32_t *)uwip_ws(ctx, "ov.selhist", sizeof(uint32_t) * 65536 * F);
+    W->sel = (uint32_t *)uwip_ws(ctx, "ov.sel", sizeof(uint32_t) * 4 * F);
+    W->counts = (uint32_t *)uwip_ws(ctx, "ov.counts", sizeof(uint32_t) * nchunks * F);
+    if (!W->gray || !W->L0 || !W->tmp || !W->Lsm || !W->flow || !W->ping || !W->Lt || !W->Lx || !W->Ly || !W->Ldet || !W->cand ||
+        !W->kc || !W->hmax || !W->khist || !W->selhist || !W->sel || !W->counts)
+        return UWIP_ERR_NOMEM;
+    return UWIP_OK;
+}
+
+// level images are stored [F][NLEV][h][w]; per-level kernels address level lv of every frame through a
+// base pointer + frame stride of NLEV*n.  The simple kernels above index frames densely (stride n), so the
+// per-level passes run on dense scratch planes and are copied into place with a strided 2-D memcpy.
+int put_level(uwip_ctx *ctx, float *dst_levels, const float *dense, int lv, int F, size_t n)
+{
+    UWIP_HIP(ctx, hipMemcpy2DAsync(dst_levels + (size_t)lv * n, sizeof(float) * n * NLEV, dense, sizeof(float) * n, sizeof(float) * n,
+                                   (size_t)F, hipMemcpyDeviceToDevice, ctx->stream));
+    return UWIP_OK;
+}
+
+// detect + describe every frame whose gray/L0 already sit in W (working size h x w)
+int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features *ft, int first_slot)
+{
+    const size_t n = (size_t)h * w;
+    const dim3 g = grid2d(w, h, F);
+    float *cur = (float *)uwip_ws(ctx, "ov.cur", n * F * 4);
+    float *dLx = (float *)uwip_ws(ctx, "ov.dLx", n * F * 4);
+    float *dLy = (float *)uwip_ws(ctx, "ov.dLy", n * F * 4);
+    float *dLd = (float *)uwip_ws(ctx, "ov.dLd", n * F * 4);
+    if (!cur || !dLx || !dLy || !dLd) return UWIP_ERR_NOMEM;
+    {
+        uwip_kscope ks(ctx, "k_ov_scale_space");
+        const ConvK K0 = gauss_kernel(H_SIGMA[0]), K1 = gauss_kernel(1.0f);
+        k_ov_conv<true><<<g, 256, 0, ctx->stream>>>(W.L0, W.tmp, h, w, K0);
+        k_ov_conv<false><<<g, 256, 0, ctx->stream>>>(W.tmp, cur, h, w, K0);
+        for (int lv = 0; lv < NLEV; ++lv) {
+            int rc = put_level(ctx, W.Lt, cur, lv, F, n);
+            if (rc) return rc;
+            k_ov_conv<true><<<g, 256, 0, ctx->stream>>>(cur, W.tmp, h, w, K1);
+            k_ov_conv<false><<<g, 256, 0, ctx->stream>>>(W.tmp, W.Lsm, h, w, K1);
+            if (lv == 0) {
+                UWIP_HIP(ctx, hipMemsetAsync(W.hmax, 0, sizeof(uint32_t) * F, ctx->stream));
+                UWIP_HIP(ctx, hipMemsetAsync(W.khist, 0, sizeof(uint32_t) * 304 * F, ctx->stream));
+                k_ov_kc<0><<<g, 256, 0, ctx->stream>>>(W.Lsm, h, w, W.hmax, W.khist);
+                k_ov_kc<1><<<g, 256, 0, ctx->stream>>>(W.Lsm, h, w, W.hmax, W.khist);
+                k_ov_kc_final<<<uwip_cdiv(F, 64), 64, 0, ctx->stream>>>(W.hmax, W.khist, W.kc, F);
+            }
+            const int s = H_SSIZE[lv];
+            k_ov_deriv1<<<g, 256, 0, ctx->stream>>>(W.Lsm, dLx, dLy, h, w, s);
+            k_ov_ldet<<<g, 256, 0, ctx->stream>>>(dLx, dLy, dLd, h, w, s);
+            rc = put_level(ctx, W.Lx, dLx, lv, F, n); if (rc) return rc;
+            rc = put_level(ctx, W.Ly, dLy, lv, F, n); if (rc) return rc;
+            rc = put_level(ctx, W.Ldet, dLd, lv, F, n); if (rc) return rc;
+            if (lv + 1 < NLEV) {
+                k_ov_flow<<<g, 256, 0, ctx->stream>>>(W.Lsm, W.kc, W.flow, h, w);
+                const float e0 = 0.5f * H_SIGMA[lv] * H_SIGMA[lv], e1 = 0.5f * H_SIGMA[lv + 1] * H_SIGMA[lv + 1];
+                float taus[32];
+                const int nt = fed_taus(e1 - e0, taus);
+                float *a = cur, *b = W.ping;
+                for (int k = 0; k < nt; ++k) {
+                    k_ov_fed<<<g, 256, 0, ctx->stream>>>(a, W.flow, b, h, w, taus[k]);
+                    std::swap(a, b);
+                }
+                if (a != cur) {        // result sits in ping: make `cur` point at it by swapping the workspaces' roles
+                    UWIP_HIP(ctx, hipMemcpyAsync(cur, a, n * F * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                }
+            }
+        }
+        UWIP_HIP(ctx, hipGetLastError());
+    }
+    const size_t n4 = n * NLEV;
+    const int nchunks = (int)((n4 + CMP_CHUNK - 1) / CMP_CHUNK);
+    Keypoint *kps = ft->d_kp + (size_t)first_slot * MAXKP;
+    int32_t *nkp = ft->d_n + first_slot;
+    {
+        uwip_kscope ks(ctx, "k_ov_detect");
+        k_ov_extrema<<<grid2d(w, h, F * NLEV), 256, 0, ctx->stream>>>(W.Ldet, W.cand, h, w);
+        UWIP_HIP(ctx, hipMemsetAsync(W.selhist, 0, sizeof(uint32_t) * 65536 * F, ctx->stream));
+        k_ov_sel_hist<0><<<dim3(64, F), 256, 0, ctx->stream>>>(W.cand, n4, W.selhist, W.sel);
+        k_ov_sel_pick<0><<<F, 256, 0, ctx->stream>>>(W.selhist, W.sel);
+        UWIP_HIP(ctx, hipMemsetAsync(W.selhist, 0, sizeof(uint32_t) * 65536 * F, ctx->stream));
+        k_ov_sel_hist<1><<<dim3(64, F), 256, 0, ctx->stream>>>(W.cand, n4, W.selhist, W.sel);
+        k_ov_sel_pick<1><<<F, 256, 0, ctx->stream>>>(W.selhist, W.sel);
+        k_ov_count<<<dim3(nchunks, F), 256, 0, ctx->stream>>>(W.cand, n4, W.sel, W.counts, nchunks);
+        k_ov_scan_chunks<<<F, 256, 0, ctx->stream>>>(W.counts, nchunks, nkp);
+        k_ov_compact<<<dim3(nchunks, F), 256, 0, ctx->stream>>>(W.cand, W.Ldet, h, w, W.sel, W.counts, nchunks, kps);
+        UWIP_HIP(ctx, hipGetLastError());
+    }
+    {
+        uwip_kscope ks(ctx, "k_ov_describe");
+        k_ov_describe<<<dim3(MAXKP, F), 64, 0, ctx->stream>>>(W.Lt, W.Lx, W.Ly, h, w, kps, nkp,
+                                                             ft->d_desc + (size_t)first_slot * MAXKP * DESC_BYTES,
+                                                             ft->d_bits + (size_t)first_slot * MAXKP * DESC_K,
+                                                             ft->d_pop + (size_t)first_slot * MAXKP);
+        UWIP_HIP(ctx, hipGetLastError());
+    }
+    return UWIP_OK;
+}
+
+}  // namespace
+
+// ---- exported entry points -------------------------------------------------------------------------------------
+
+UWIP_API int uwip_features_create(uwip_ctx *ctx, int max_frames, uwip_features **out)
+{
+    if (!ctx || !out) return UWIP_ERR_INVALID;
+    UWIP_REQUIRE(ctx, max_frames >= 1 && max_frames <= 4096, "max_frames must be in [1,4096]");
+    uwip_features *f = new (std::nothrow) uwip_features();
+    if (!f) return UWIP_ERR_NOMEM;
+    f->ctx = ctx; f->capacity = max_frames;
+    const size_t K = (size_t)max_frames * MAXKP;
+    if (hipMalloc(&f->d_kp, K * sizeof(Keypoint)) != hipSuccess || hipMalloc(&f->d_desc, K * DESC_BYTES) != hipSuccess ||
+        hipMalloc(&f->d_bits, K * DESC_K) != hipSuccess || hipMalloc(&f->d_pop, K * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(&f->d_n, sizeof(int32_t) * max_frames) != hipSuccess) {
+        (void)hipFree(f->d_kp); (void)hipFree(f->d_desc); (void)hipFree(f->d_bits); (void)hipFree(f->d_pop); (void)hipFree(f->d_n);
+        delete f;
+        return ctx->fail(UWIP_ERR_NOMEM, "feature set hipMalloc");
+    }
+    (void)hipMemsetAsync(f->d_n, 0, sizeof(int32_t) * max_frames, ctx->stream);
+    (void)hipMemsetAsync(f->d_bits, 0, K * DESC_K, ctx->stream);
+    (void)hipMemsetAsync(f->d_pop, 0, K * sizeof(int32_t), ctx->stream);
+    *out = f;
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_features_destroy(uwip_features *f)
+{
+    if (!f) return UWIP_OK;
+    (void)hipStreamSynchronize(f->ctx->stream);
+    (void)hipFree(f->d_kp); (void)hipFree(f->d_desc); (void)hipFree(f->d_bits); (void)hipFree(f->d_pop); (void)hipFree(f->d_n);
+    delete f;
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_overlap_working_size(int rows, int cols, int *orows, int *ocols)
+{
+    if (!orows || !ocols || rows <= 0 || cols <= 0) return UWIP_ERR_INVALID;
+    resize_dims(rows, cols, TW, orows, ocols);
+    return UWIP_OK;
+}
+
+// frames: full-resolution BGR (resized to 640 wide inside, main.cpp:242,311) or, when `already_gray`
+// is set, 8UC1 planes already at the working size.  Fills slots [first_slot, first_slot+frames).
+UWIP_API int uwip_overlap_detect(uwip_ctx *ctx, const uwip_batch_u8 *frames, uwip_features *feats, int first_slot)
+{
+    int rc = uwip_check_batch(ctx, frames, 0);
+    if (rc) return rc;
+    UWIP_REQUIRE(ctx, feats != nullptr && feats->ctx == ctx, "feature set belongs to another context");
+    UWIP_REQUIRE(ctx, first_slot >= 0 && first_slot + frames->frames <= feats->capacity, "feature set too small");
+    if (frames->frames == 0) return UWIP_OK;
+    UWIP_REQUIRE(ctx, !uwip_batch_empty(frames), "empty image");           // calcOverlap returns -1 there
+    const int F = frames->frames;
+    int h, w;
+    if (frames->channels == 3) resize_dims(frames->rows, frames->cols, TW, &h, &w);
+    else { h = frames->rows; w = frames->cols; }
+    UWIP_REQUIRE(ctx, h >= 2 * BORDER + 3 && w >= 2 * BORDER + 3, "working image too small");
+    UWIP_REQUIRE(ctx, feats->w == 0 || (feats->w == w && feats->h == h), "feature set holds frames of another size");
+    OvWork W;
+    rc = alloc_work(ctx, F, h, w, &W);
+    if (rc) return rc;
+    const size_t n = (size_t)h * w;
+    if (frames->channels == 3) {
+        const uint8_t *tx = (const uint8_t *)resize_table(ctx, frames->cols, w);
+        const uint8_t *ty = (const uint8_t *)resize_table(ctx, frames->rows, h);
+        if (!tx || !ty) return UWIP_ERR_NOMEM;
+        uwip_kscope ks(ctx, "k_ov_resize_gray");
+        k_ov_resize_gray<<<grid2d(w, h, F), 256, 0, ctx->stream>>>(
+            (const uint8_t *)frames->data, frames->step, frames->frame_stride, frames->rows, frames->cols, h, w,
+            (const int *)tx, (const short *)(tx + (size_t)w * 4), (const short *)(tx + (size_t)w * 6),
+            (const int *)ty, (const short *)(ty + (size_t)h * 4), (const short *)(ty + (size_t)h * 6), W.gray, W.L0);
+        UWIP_HIP(ctx, hipGetLastError());
+    } else {
+        for (int f = 0; f < F; ++f)
+            UWIP_HIP(ctx, hipMemcpy2DAsync(W.gray + (size_t)f * n, (size_t)w, (const uint8_t *)frames->data + (size_t)f * frames->frame_stride,
+                                           frames->step, (size_t)w, (size_t)h, hipMemcpyDeviceToDevice, ctx->stream));
+        k_ov_gray_to_L0<<<uwip_cdiv(n * F, 256), 256, 0, ctx->stream>>>(W.gray, W.L0, n * F);
+        UWIP_HIP(ctx, hipGetLastError());
+    }
+    feats->w = w; feats->h = h;
+    feats->frames = std::max(feats->frames, first_slot + F);
+    return detect_describe(ctx, W, F, h, w, feats, first_slot);
+}
+
+// tap for tests: one slot's keypoints / packed descriptors to the host
+UWIP_API int uwip_features_download(uwip_ctx *ctx, const uwip_features *feats, int slot, void *h_kps /*[2048] 32-byte records*/,
+                                    uint8_t *h_desc /*[2048][64]*/, int32_t *h_count)
+{
+    if (!ctx || !feats) return UWIP_ERR_INVALID;
+    UWIP_REQUIRE(ctx, slot >= 0 && slot < feats->capacity, "slot out of range");
+    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h_count) UWIP_HIP(ctx, hipMemcpy(h_count, feats->d_n + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (h_kps) UWIP_HIP(ctx, hipMemcpy(h_kps, feats->d_kp + (size_t)slot * MAXKP, sizeof(Keypoint) * MAXKP, hipMemcpyDeviceToHost));
+    if (h_desc) UWIP_HIP(ctx, hipMemcpy(h_desc, feats->d_desc + (size_t)slot * MAXKP * DESC_BYTES, (size_t)MAXKP * DESC_BYTES, hipMemcpyDeviceToHost));
+    return UWIP_OK;
+}
+
+// scale-space tap for tests: level images of slot-0 work buffers after the last detect call
+UWIP_API int uwip_overlap_debug_level(uwip_ctx *ctx, int frame, int level, int rows, int cols, float *h_Lt, float *h_Lx,
+                                      float *h_Ly, float *h_Ldet, float *h_kcontrast)
+{
+    if (!ctx) return UWIP_ERR_INVALID;
+    UWIP_REQUIRE(ctx, level >= 0 && level < NLEV && frame >= 0, "bad level/frame");
+    const size_t n = (size_t)rows * cols;
+    auto get = [&](const char *name) -> float * {
+        auto it = ctx->ws.find(name);
+        return it == ctx->ws.end() ? nullptr : (float *)it->second.ptr;
+    };
+    float *Lt = get("ov.Lt"), *Lx = get("ov.Lx"), *Ly = get("ov.Ly"), *Ld = get("ov.Ldet"), *kc = get("ov.kc");
+    UWIP_REQUIRE(ctx, Lt && Lx && Ly && Ld && kc, "no detect call yet");
+    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t off = ((size_t)frame * NLEV + level) * n;
+    if (h_Lt) UWIP_HIP(ctx, hipMemcpy(h_Lt, Lt + off, n * 4, hipMemcpyDeviceToHost));
+    if (h_Lx) UWIP_HIP(ctx, hipMemcpy(h_Lx, Lx + off, n * 4, hipMemcpyDeviceToHost));
+    if (h_Ly) UWIP_HIP(ctx, hipMemcpy(h_Ly, Ly + off, n * 4, hipMemcpyDeviceToHost));
+    if (h_Ldet) UWIP_HIP(ctx, hipMemcpy(h_Ldet, Ld + off, n * 4, hipMemcpyDeviceToHost));
+    if (h_kcontrast) UWIP_HIP(ctx, hipMemcpy(h_kcontrast, kc + frame, 4, hipMemcpyDeviceToHost));
+    return UWIP_OK;
+}
+
+// match query slots against train slots and turn each pair into an overlap ratio.
+// h_pair_q / h_pair_t: host arrays of slot indices (query = object frame, train = key frame).
+// d_ratio [npairs]: overlap ratio or -2.0 (videostrip.cpp:252-256,272).  d_info (may be NULL) [npairs][8]:
+// nkp_obj, nkp_key, ngood, ninliers, overlap pixel count.  d_H (may be NULL) [npairs][9].
+// d_match_idx / d_match_dist (may be NULL) [npairs][2048][2]: the kNN(2) result.
+UWIP_API int uwip_overlap_match(uwip_ctx *ctx, const uwip_features *fq, const uwip_features *ft, const int32_t *h_pair_q,
+                                const int32_t *h_pair_t, int npairs, int videoWidth, int videoHeight, uint32_t seed,
+                                float *d_ratio, int32_t *d_info, double *d_H, int32_t *d_match_idx, int32_t *d_match_dist)
+{
+    if (!ctx) return UWIP_ERR_INVALID;
+    UWIP_REQUIRE(ctx, fq && ft && fq->ctx == ctx && ft->ctx == ctx, "bad feature sets");
+    UWIP_REQUIRE(ctx, npairs >= 0 && npairs <= 65535, "npairs out of range");
+    if (npairs == 0) return UWIP_OK;
+    UWIP_REQUIRE(ctx, h_pair_q && h_pair_t && d_ratio, "null buffer");
+    UWIP_REQUIRE(ctx, fq->w == ft->w && fq->h == ft->h && fq->w > 0, "feature sets of different working sizes");
+    for (int p = 0; p < npairs; ++p)
+        UWIP_REQUIRE(ctx, h_pair_q[p] >= 0 && h_pair_q[p] < fq->capacity && h_pair_t[p] >= 0 && h_pair_t[p] < ft->capacity, "pair slot out of range");
+    int32_t *h_pairs = (int32_t *)uwip_host_ws(ctx, "ov.pairs", sizeof(int32_t) * 2 * (size_t)npairs);
+    int32_t *d_pairs = (int32_t *)uwip_ws(ctx, "ov.pairs", sizeof(int32_t) * 2 * (size_t)npairs);
+    int32_t *m_idx = d_match_idx ? d_match_idx : (int32_t *)uwip_ws(ctx, "ov.midx", sizeof(int32_t) * 2 * MAXKP * (size_t)npairs);
+    int32_t *m_dist = d_match_dist ? d_match_dist : (int32_t *)uwip_ws(ctx, "ov.mdist", sizeof(int32_t) * 2 * MAXKP * (size_t)npairs);
+    int32_t *info = d_info ? d_info : (int32_t *)uwip_ws(ctx, "ov.info", sizeof(int32_t) * 8 * (size_t)npairs);
+    if (!h_pairs || !d_pairs || !m_idx || !m_dist || !info) return UWIP_ERR_NOMEM;
+    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));          // pinned staging reuse
+    memcpy(h_pairs, h_pair_q, sizeof(int32_t) * npairs);
+    memcpy(h_pairs + npairs, h_pair_t, sizeof(int32_t) * npairs);
+    UWIP_HIP(ctx, hipMemcpyAsync(d_pairs, h_pairs, sizeof(int32_t) * 2 * (size_t)npairs, hipMemcpyHostToDevice, ctx->stream));
+    {
+        uwip_kscope ks(ctx, "k_ov_match");
+        const size_t lds = (size_t)64 * MT_ROW;
+        k_ov_match<<<dim3(MAXKP / 64, npairs), 256, lds, ctx->stream>>>(fq->d_bits, fq->d_pop, fq->d_n, ft->d_bits, ft->d_pop, ft->d_n,
+                                                                       d_pairs, d_pairs + npairs, m_idx, m_dist);
+        UWIP_HIP(ctx, hipGetLastError());
+    }
+    {
+        uwip_kscope ks(ctx, "k_ov_geometry");
+        const size_t lds = (size_t)MAXKP * 16 + MAXKP + (size_t)TH * MASK_WORDS * 4 + (size_t)TH * 4;
+        static bool attr_set = false;          // > 64 KiB of dynamic LDS needs an explicit opt-in
+        if (!attr_set) {
+            UWIP_HIP(ctx, hipFuncSetAttribute((const void *)k_ov_geometry, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        k_ov_geometry<<<npairs, 256, lds, ctx->stream>>>(fq->d_kp, ft->d_kp, fq->d_n, ft->d_n, d_pairs, d_pairs + npairs, m_idx, m_dist,
+                                                        fq->w, fq->h, videoWidth, videoHeight, seed, d_ratio, info, d_H);
+        UWIP_HIP(ctx, hipGetLastError());
+    }
+    return UWIP_OK;
+}
+
+// overlapArea(Mat H), videostrip.cpp:291-319, for n homographies (device, row-major 3x3 doubles)
+UWIP_API int uwip_overlapArea(uwip_ctx *ctx, const double *d_H, int n, int videoWidth, int videoHeight, float *d_ratio,
+                              int32_t *d_count)
+{
+    if (!ctx) return UWIP_ERR_INVALID;
+    UWIP_REQUIRE(ctx, n >= 0, "negative count");
+    if (n == 0) return UWIP_OK;
+    UWIP_REQUIRE(ctx, d_H && d_ratio, "null buffer");
+    uwip_kscope ks(ctx, "k_ov_area_only");
+    k_ov_area_only<<<n, 256, 0, ctx->stream>>>(d_H, videoWidth, videoHeight, d_ratio, d_count);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}
+
+// calcBlur(Mat frame), videostrip.cpp:170-184, per frame of a BGR batch ALREADY at the working size
+// (the reference calls it on res_frame, main.cpp:338,355): d_blur [frames].
+UWIP_API int uwip_calcBlur(uwip_ctx *ctx, const uwip_batch_u8 *frames, float *d_blur)
+{
+    int rc = uwip_check_batch(ctx, frames, 3);
+    if (rc) return rc;
+    if (frames->frames == 0) return UWIP_OK;
+    UWIP_REQUIRE(ctx, !uwip_batch_empty(frames) && d_blur, "empty image or null output");
+    const int F = frames->frames, h = frames->rows, w = frames->cols;
+    const size_t n = (size_t)h * w;
+    uint8_t *gray = (uint8_t *)uwip_ws(ctx, "blur.gray", n * F);
+    float *L0 = (float *)uwip_ws(ctx, "blur.L0", n * F * 4);
+    const int nb = 64;
+    double *part = (double *)uwip_ws(ctx, "blur.part", sizeof(double) * 2 * nb * F);
+    if (!gray || !L0 || !part) return UWIP_ERR_NOMEM;
+    const uint8_t *tx = (const uint8_t *)resize_table(ctx, w, w), *ty = (const uint8_t *)resize_table(ctx, h, h);
+    if (!tx || !ty) return UWIP_ERR_NOMEM;
+    uwip_kscope ks(ctx, "k_ov_blur");
+    // identity "resize" = the fused BGR2GRAY pass
+    k_ov_resize_gray<<<grid2d(w, h, F), 256, 0, ctx->stream>>>((const uint8_t *)frames->data, frames->step, frames->frame_stride, h, w, h, w,
+                                                              (const int *)tx, (const short *)(tx + (size_t)w * 4), (const short *)(tx + (size_t)w * 6),
+                                                              (const int *)ty, (const short *)(ty + (size_t)h * 4), (const short *)(ty + (size_t)h * 6),
+                                                              gray, L0);
+    k_ov_blur<<<dim3(nb, F), 256, 0, ctx->stream>>>(gray, h, w, part);
+    k_ov_blur_final<<<uwip_cdiv(F, 64), 64, 0, ctx->stream>>>(part, nb, (double)n, d_blur, F);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}

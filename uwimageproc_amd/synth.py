@@ -46,3 +46,56 @@ def adversarial(kind: str, rows: int, cols: int, seed: int = 7) -> np.ndarray:
         r = (np.arange(cols, dtype=np.int64) * 256 // max(cols, 1)).astype(np.uint8)
         return np.repeat(np.repeat(r[None, :, None], rows, axis=0), 3, axis=2)
     raise ValueError(kind)
+
+
+def _texture(seed: int, rows: int, cols: int) -> np.ndarray:
+    """Corner-rich grey texture in [0,1]: low-frequency field + random rectangles and discs."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.arange(rows, dtype=np.float32), np.arange(cols, dtype=np.float32), indexing="ij")
+    t = np.zeros((rows, cols), np.float32)
+    for _ in range(4):
+        period = rng.uniform(120.0, 500.0)
+        theta = rng.uniform(0.0, 2 * np.pi)
+        t += np.cos(np.float32(2 * np.pi / period) * (xx * np.float32(np.cos(theta)) + yy * np.float32(np.sin(theta))) + np.float32(rng.uniform(0, 6.28)))
+    t = (t - t.min()) / max(float(t.max() - t.min()), 1e-6) * 0.5 + 0.1
+    nblobs = max(40, rows * cols // 6000)
+    for _ in range(nblobs):
+        cy, cx = rng.integers(0, rows), rng.integers(0, cols)
+        a = rng.uniform(0.15, 0.45) * (1 if rng.random() < 0.5 else -1)
+        if rng.random() < 0.5:
+            hh, ww = rng.integers(6, 40), rng.integers(6, 40)
+            t[max(cy - hh, 0):cy + hh, max(cx - ww, 0):cx + ww] += np.float32(a)
+        else:
+            r = rng.integers(5, 28)
+            y0, y1, x0, x1 = max(cy - r, 0), min(cy + r + 1, rows), max(cx - r, 0), min(cx + r + 1, cols)
+            m = (yy[y0:y1, x0:x1] - cy) ** 2 + (xx[y0:y1, x0:x1] - cx) ** 2 <= r * r
+            t[y0:y1, x0:x1][m] += np.float32(a)
+    return np.clip(t, 0.0, 1.0)
+
+
+def uw_stream(first: int, frames: int, rows: int, cols: int, step_frac: float = 0.03, seed0: int = 1234):
+    """Consecutive frames of a camera translating over one corner-rich scene: frame i is the
+    window of a larger texture at integer offset (dx_i, dy_i) = i * (step_frac*cols, step_frac*cols/3),
+    so the true homography between frames i and j is a pure translation.  Underwater colour cast
+    and per-frame noise (seed = seed0 + first + i) as in uw_frame."""
+    sx = max(1, int(round(step_frac * cols)))
+    sy = max(1, sx // 3)
+    total = first + frames
+    tex = _texture(seed0, rows + sy * (total + 1), cols + sx * (total + 1))
+    out = np.empty((frames, rows, cols, 3), np.uint8)
+    for i in range(frames):
+        k = first + i
+        win = tex[k * sy:k * sy + rows, k * sx:k * sx + cols] * 200.0
+        rng = np.random.default_rng(seed0 + k)
+        f = np.empty((rows, cols, 3), np.float32)
+        f[..., 0] = win * 1.0 + 50.0
+        f[..., 1] = win * 0.8 + 35.0
+        f[..., 2] = win * 0.35 + 10.0
+        f += rng.integers(-4, 5, size=f.shape).astype(np.float32)
+        out[i] = np.clip(np.rint(f), 0, 255).astype(np.uint8)
+    return out
+
+
+def uw_stream_shift(cols: int, step_frac: float = 0.03):
+    sx = max(1, int(round(step_frac * cols)))
+    return sx, max(1, sx // 3)

@@ -1,0 +1,127 @@
+"""Host-side mirror of modules/videostrip/{include/videostrip.hpp,src/videostrip.cpp}
+and of the selector loop in src/main.cpp:300-394, over the C ABI.
+
+``keyframe`` mirrors ``struct keyframe`` (videostrip.hpp:62-68): the key frame image
+plus its cached keypoints/descriptors (here: a slot of a device feature set).
+``videoWidth`` / ``videoHeight`` are module globals as in the reference
+(main.cpp:45-49, extern in videostrip.cpp:29-33)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._native import Context, batch_of
+
+TARGET_WIDTH, TARGET_HEIGHT = 640, 480        # videostrip.hpp:48-49
+OVERLAP_MIN = 0.4                             # videostrip.hpp:50
+DEFAULT_KWINDOW = 11                          # videostrip.hpp:51
+
+videoWidth, videoHeight = 0, 0                # main.cpp:45-46
+
+KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("response", "f4"), ("level", "i4"), ("xi", "i4"), ("yi", "i4"),
+                     ("pad0", "i4"), ("pad1", "i4")])
+
+
+class Features:
+    """Opaque device feature set (uwip_features): `capacity` frame slots."""
+
+    def __init__(self, ctx: Context, capacity: int):
+        self.ctx, self.capacity = ctx, capacity
+        h = C.c_void_p()
+        ctx.call("uwip_features_create", int(capacity), C.byref(h))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._l.uwip_features_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def detect(self, frames: torch.Tensor, first_slot: int = 0):
+        b = batch_of(frames)
+        torch.cuda.current_stream(frames.device).synchronize()
+        self.ctx.call("uwip_overlap_detect", C.byref(b), self._h, int(first_slot))
+
+    def download(self, slot: int):
+        kps = np.zeros(2048, KP_DTYPE)
+        desc = np.zeros((2048, 64), np.uint8)
+        n = C.c_int32(0)
+        self.ctx.call("uwip_features_download", self._h, int(slot), C.c_void_p(kps.ctypes.data), C.c_void_p(desc.ctypes.data), C.byref(n))
+        return kps[:n.value].copy(), desc[:n.value].copy()
+
+
+def match_pairs(ctx: Context, fq: Features, ft: Features, pair_q, pair_t, vw: int, vh: int, seed: int = 1,
+                want_matches: bool = False):
+    """kNN(2) + ratio test + homography + overlapArea for (object slot, key slot) pairs."""
+    n = len(pair_q)
+    dev = torch.device("cuda", ctx.device)
+    ratio = torch.empty((n,), dtype=torch.float32, device=dev)
+    info = torch.zeros((n, 8), dtype=torch.int32, device=dev)
+    H = torch.zeros((n, 9), dtype=torch.float64, device=dev)
+    midx = torch.full((n, 2048, 2), -1, dtype=torch.int32, device=dev) if want_matches else None
+    mdist = torch.full((n, 2048, 2), -1, dtype=torch.int32, device=dev) if want_matches else None
+    pq = (C.c_int32 * n)(*[int(v) for v in pair_q])
+    pt = (C.c_int32 * n)(*[int(v) for v in pair_t])
+    torch.cuda.synchronize()
+    ctx.call("uwip_overlap_match", fq._h, ft._h, pq, pt, n, int(vw), int(vh), int(seed), C.c_void_p(ratio.data_ptr()),
+             C.c_void_p(info.data_ptr()), C.c_void_p(H.data_ptr()),
+             C.c_void_p(midx.data_ptr()) if want_matches else None, C.c_void_p(mdist.data_ptr()) if want_matches else None)
+    ctx.sync()
+    out = {"ratio": ratio, "info": info, "H": H.reshape(n, 3, 3)}
+    if want_matches:
+        out["idx"], out["dist"] = midx, mdist
+    return out
+
+
+class keyframe:
+    """struct keyframe (videostrip.hpp:62-68)."""
+
+    def __init__(self, ctx: Context, img: torch.Tensor):
+        self.ctx = ctx
+        self.img = img
+        self.new_img = True
+        self.feats = Features(ctx, 1)
+
+
+def calcOverlap(ctx: Context, kframe: keyframe, img_object: torch.Tensor, seed: int = 1) -> float:
+    """videostrip.cpp:192-289.  ``img_object`` / ``kframe.img`` are full-resolution BGR frames
+    (the 640-wide resize of main.cpp:311 happens inside).  Returns the overlap ratio, -1 for
+    empty input, -2.0 when no homography can be estimated."""
+    if img_object is None or kframe.img is None or img_object.numel() == 0 or kframe.img.numel() == 0:
+        print(" --(!) Error reading images ")
+        return -1.0
+    if kframe.new_img:
+        kframe.feats.detect(kframe.img, 0)
+        kframe.new_img = False
+    obj = Features(ctx, 1)
+    obj.detect(img_object, 0)
+    r = match_pairs(ctx, obj, kframe.feats, [0], [0], videoWidth, videoHeight, seed)
+    obj.close()
+    return float(r["ratio"].cpu()[0])
+
+
+def overlapArea(ctx: Context, H) -> float:
+    """videostrip.cpp:291-319 for one 3x3 homography (array-like, double)."""
+    Hd = torch.as_tensor(np.asarray(H, dtype=np.float64).reshape(1, 9)).cuda()
+    out = torch.empty((1,), dtype=torch.float32, device=Hd.device)
+    torch.cuda.synchronize()
+    ctx.call("uwip_overlapArea", C.c_void_p(Hd.data_ptr()), 1, int(videoWidth), int(videoHeight), C.c_void_p(out.data_ptr()), None)
+    ctx.sync()
+    return float(out.cpu()[0])
+
+
+def calcBlur(ctx: Context, frame: torch.Tensor):
+    """videostrip.cpp:170-184 per BGR frame -> float (or a tensor for a batch)."""
+    b = batch_of(frame)
+    out = torch.empty((b.frames,), dtype=torch.float32, device=frame.device)
+    torch.cuda.current_stream(frame.device).synchronize()
+    ctx.call("uwip_calcBlur", C.byref(b), C.c_void_p(out.data_ptr()))
+    ctx.sync()
+    return float(out.cpu()[0]) if frame.dim() == 3 else out
