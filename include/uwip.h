@@ -163,6 +163,11 @@ int uwip_aclahe_select(const float *h_entropy, int frames, int32_t *h_bs, int32_
 int uwip_aclahe_auto(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst,
                      int residual_rule, int32_t *h_bs, int32_t *h_cl);
 
+/* "transform back image" (aclahe.cpp:216 stub): cvtColor(BGR2HSV), replace V by
+ * v_new (the CLAHE'd plane), cvtColor(HSV2BGR), all 8-bit.  bgr_out may alias bgr. */
+int uwip_hsv_replace_v(uwip_ctx *ctx, const uwip_batch_u8 *bgr, const uwip_batch_u8 *v_new,
+                       const uwip_batch_u8 *bgr_out);
+
 /* ---- bgdehaze (D1-D6) ---------------------------------------------------- */
 /* All real-valued results are float64, as in the reference.  The input is the
  * uint8 BGR frame cv2.imread returns; normI = (I - min)/(max - min)
@@ -226,6 +231,9 @@ typedef struct uwip_keypoint {
 
 int uwip_features_create(uwip_ctx *ctx, int max_frames, uwip_features **out);
 int uwip_features_destroy(uwip_features *feats);
+/* copy one slot's cached keypoints/descriptors (kframe->keypoints/descriptors) to another slot */
+int uwip_features_copy(uwip_ctx *ctx, const uwip_features *src, int src_slot, uwip_features *dst,
+                       int dst_slot);
 /* working size for a rows x cols frame: cv::resize(frame, Size(), f, f), f = 640/cols */
 int uwip_overlap_working_size(int rows, int cols, int *orows, int *ocols);
 /* frames: full-resolution CV_8UC3 BGR (resized inside) or CV_8UC1 planes already at the

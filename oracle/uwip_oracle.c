@@ -416,3 +416,57 @@ ORC_API float orc_calcBlur(const uint8_t *bgr, int rows, int cols, size_t step)
     free(gray);
     return r;
 }
+
+/* ------------------------------------------------------------------ */
+/* "transform back image" (modules/aclahe/src/aclahe.cpp:216 stub):       */
+/* cvtColor(BGR2HSV), replace V, cvtColor(HSV2BGR), 8-bit, restating      */
+/* OpenCV 3.4 color.cpp (RGB2HSV_b integer tables, HSV2RGB_b via float).  */
+/* parity unpinned.                                                       */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_bgr_to_hsv_px(int b, int g, int r, int *h, int *s, int *v)
+{
+    int vv = b > g ? b : g; vv = vv > r ? vv : r;
+    int vmin = b < g ? b : g; vmin = vmin < r ? vmin : r;
+    int diff = vv - vmin;
+    int vr = vv == r ? -1 : 0, vg = vv == g ? -1 : 0;
+    int sdiv = vv ? (int)lrint((255 << 12) / (1. * vv)) : 0;
+    int hdiv = diff ? (int)lrint((180 << 12) / (6. * diff)) : 0;
+    *s = (diff * sdiv + (1 << 11)) >> 12;
+    int hh = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    hh = (hh * hdiv + (1 << 11)) >> 12;
+    hh += hh < 0 ? 180 : 0;
+    *h = hh; *v = vv;
+}
+
+ORC_API void orc_hsv_to_bgr_px(int h, int s, int v, uint8_t out[3])
+{
+    static const int sector_data[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    float hf = (float)h, sf = (float)s * (1.f / 255.f), vf = (float)v * (1.f / 255.f);
+    float b, g, r;
+    if (sf == 0) {
+        b = g = r = vf;
+    } else {
+        float tab[4];
+        hf *= (6.f / 180.f);
+        if (hf < 0) do hf += 6; while (hf < 0);
+        else if (hf >= 6) do hf -= 6; while (hf >= 6);
+        int sector = (int)floorf(hf);
+        hf -= (float)sector;
+        if ((unsigned)sector >= 6u) { sector = 0; hf = 0.f; }
+        tab[0] = vf; tab[1] = vf * (1.f - sf); tab[2] = vf * (1.f - sf * hf); tab[3] = vf * (1.f - sf * (1.f - hf));
+        b = tab[sector_data[sector][0]]; g = tab[sector_data[sector][1]]; r = tab[sector_data[sector][2]];
+    }
+    out[0] = sat_u8_rne(b * 255.f); out[1] = sat_u8_rne(g * 255.f); out[2] = sat_u8_rne(r * 255.f);
+}
+
+ORC_API void orc_hsv_replace_v(const uint8_t *bgr, int rows, int cols, size_t step, const uint8_t *vnew, size_t vstep,
+                               uint8_t *out, size_t ostep)
+{
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const uint8_t *p = bgr + (size_t)y * step + (size_t)x * 3;
+            int h, s, v;
+            orc_bgr_to_hsv_px(p[0], p[1], p[2], &h, &s, &v);
+            orc_hsv_to_bgr_px(h, s, vnew[(size_t)y * vstep + x], out + (size_t)y * ostep + (size_t)x * 3);
+        }
+}

@@ -66,6 +66,29 @@ class Oracle:
         L.orc_calcOverlap.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_uint32,
                                       C.POINTER(C.c_int32), C.POINTER(C.c_double)]
 
+        L.orc_bgr_to_hsv_px.restype = None
+        L.orc_bgr_to_hsv_px.argtypes = [C.c_int] * 3 + [C.POINTER(C.c_int)] * 3
+        L.orc_hsv_to_bgr_px.restype = None
+        L.orc_hsv_to_bgr_px.argtypes = [C.c_int] * 3 + [u8p]
+        L.orc_hsv_replace_v.restype = None
+        L.orc_hsv_replace_v.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t, u8p, C.c_size_t]
+
+    def bgr_to_hsv_px(self, b, g, r):
+        v = [C.c_int(0) for _ in range(3)]
+        self.lib.orc_bgr_to_hsv_px(b, g, r, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)
+
+    def hsv_to_bgr_px(self, h, s, v):
+        out = np.zeros(3, np.uint8)
+        self.lib.orc_hsv_to_bgr_px(h, s, v, out)
+        return tuple(int(x) for x in out)
+
+    def hsv_replace_v(self, img, vnew):
+        img, vnew = np.ascontiguousarray(img), np.ascontiguousarray(vnew)
+        out = np.zeros_like(img)
+        self.lib.orc_hsv_replace_v(img, img.shape[0], img.shape[1], img.strides[0], vnew, vnew.strides[0], out, out.strides[0])
+        return out
+
     # ---- overlap wrappers ----
     def resize_dims(self, rows, cols, target_w=640):
         a, b = C.c_int(0), C.c_int(0)

@@ -113,3 +113,36 @@ def test_sweep_1080p_properties(ctx, orc):
             e = float(aclahe.aclaheEntropy(ctx, c.apply(t)).cpu()[0])
             assert abs(tab[gi, ci] - e) <= 1e-6, (g, ci)
     assert abs(tab[2, 6] - orc.entropy(orc.clahe(src, 3.0, 8, 8))) <= 1e-5
+
+
+def test_hsv_replace_v_bit_exact(ctx, orc):
+    import ctypes as C
+    from uwimageproc_amd import batch_of
+    for shape in ((37, 53), (270, 480)):
+        img = synth.adversarial("random", *shape) if shape[0] == 37 else synth.uw_frame(9, *shape)
+        vnew = orc.clahe(orc.bgr_to_v(img), 3.0, 4, 4)
+        t, v = _dev(img), _dev(vnew)
+        out = torch.empty_like(t)
+        tb, vb, ob = batch_of(t), batch_of(v), batch_of(out)
+        torch.cuda.synchronize()
+        ctx.call("uwip_hsv_replace_v", C.byref(tb), C.byref(vb), C.byref(ob))
+        ctx.sync()
+        assert np.array_equal(out.cpu().numpy(), orc.hsv_replace_v(img, vnew))
+
+
+def test_aclahe_auto_matches_staged_path(ctx, orc):
+    import ctypes as C
+    from uwimageproc_amd import batch_of
+    frames = np.stack([_v(orc, 80 + i, 135, 240) for i in range(5)])
+    t = _dev(frames)
+    out = torch.empty_like(t)
+    bs, cl = (C.c_int32 * 5)(), (C.c_int32 * 5)()
+    tb, ob = batch_of(t), batch_of(out)
+    torch.cuda.synchronize()
+    ctx.call("uwip_aclahe_auto", C.byref(tb), C.byref(ob), 0, bs, cl)
+    ctx.sync()
+    got = out.cpu().numpy()
+    for f in range(5):
+        ebs, ecl = aclahe.select_parameters(orc.sweep(frames[f]))          # scipy mirror on the oracle's table
+        assert (bs[f], cl[f]) == (ebs, ecl)
+        assert np.array_equal(got[f], orc.clahe(frames[f], float(ecl), ebs, ebs))

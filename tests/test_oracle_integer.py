@@ -280,3 +280,23 @@ def test_native_knee_matches_scipy_mirror(orc):
             k = C.c_int32(0)
             nat.lib().uwip_aclahe_knee(xs.ctypes.data_as(C.POINTER(C.c_float)), ys.ctypes.data_as(C.POINTER(C.c_float)), C.byref(k))
             assert k.value == aclahe.knee_index(xs, ys)
+
+
+def test_hsv_known_values(orc):
+    # cvtColor(BGR2HSV) 8-bit: H in [0,180), S, V in [0,255]
+    assert orc.bgr_to_hsv_px(0, 0, 255) == (0, 255, 255)        # red
+    assert orc.bgr_to_hsv_px(0, 255, 0) == (60, 255, 255)       # green
+    assert orc.bgr_to_hsv_px(255, 0, 0) == (120, 255, 255)      # blue
+    assert orc.bgr_to_hsv_px(128, 128, 128) == (0, 0, 128)      # grey
+    assert orc.bgr_to_hsv_px(0, 255, 255) == (30, 255, 255)     # yellow
+    # and back
+    assert orc.hsv_to_bgr_px(0, 255, 255) == (0, 0, 255)
+    assert orc.hsv_to_bgr_px(60, 255, 255) == (0, 255, 0)
+    assert orc.hsv_to_bgr_px(120, 255, 255) == (255, 0, 0)
+    assert orc.hsv_to_bgr_px(17, 0, 99) == (99, 99, 99)
+    # replacing V by itself is the HSV round trip: grey stays exact, colours move by a few LSB at most
+    img = synth.uw_frame(4, 24, 40)
+    rt = orc.hsv_replace_v(img, img.max(axis=2))
+    assert np.abs(rt.astype(int) - img.astype(int)).max() <= 3
+    grey = np.repeat(img[..., :1], 3, axis=2)
+    assert np.array_equal(orc.hsv_replace_v(grey, grey[..., 0]), grey)

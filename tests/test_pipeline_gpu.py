@@ -1,0 +1,60 @@
+"""GPU: the whole pipe (bgdehaze -> histretch -> aclahe -> overlap) against the oracle chained the
+same way, on a small stream.  The dehaze tail is ill-conditioned w.r.t. 1-ulp differences (see
+test_dehaze_gpu), so the chain is re-synchronised after dehaze: the oracle continues from the
+device's dehaze output, and every later stage must then match exactly."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from uwimageproc_amd import aclahe, synth
+from uwimageproc_amd.pipeline import FramePipe
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import dehaze_oracle as dz  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_pipe_small_stream(orc):
+    F, H, W = 3, 270, 480
+    frames = synth.uw_stream(0, F, H, W)
+    pipe = FramePipe(0, F, H, W, video_size=(640, 480))
+    src = torch.from_numpy(frames).cuda()
+    pipe.stage_dehaze(src)
+    torch.cuda.synchronize()
+    dehazed = pipe.work.cpu().numpy().copy()
+    for f in range(F):
+        exp = dz.to_u8(dz.adaptiveExp_map(dz.normalize_input(frames[f]), 15, guard_s=True))
+        diff = np.abs(dehazed[f].astype(int) - exp.astype(int))
+        assert diff.max() <= 1 and (diff != 0).mean() <= 1e-2
+    pipe.stage_histretch()
+    pipe.stage_aclahe()
+    pipe.stage_overlap()
+    torch.cuda.synchronize()
+    out = pipe.work.cpu().numpy()
+    ratios = pipe.ratio.cpu().numpy()
+    exp_frames = []
+    for f in range(F):
+        st, _ = orc.histretch(dehazed[f], "RGB")
+        v = orc.bgr_to_v(st)
+        bs, cl = aclahe.select_parameters(orc.sweep(v))
+        assert pipe.params[f] == (bs, cl)
+        e = orc.hsv_replace_v(st, orc.clahe(v, float(cl), bs, bs))
+        assert np.array_equal(out[f], e), f
+        exp_frames.append(e)
+    for f in range(F):
+        key = exp_frames[f - 1] if f > 0 else exp_frames[0]
+        er, info, _ = orc.calcOverlap(key, exp_frames[f], 640, 480, seed=1)
+        assert abs(ratios[f] - er) <= 1e-6, (f, ratios[f], er)
+    # second batch: frame 0 is matched against the previous batch's last frame
+    frames2 = synth.uw_stream(F, F, H, W)
+    pipe.run(torch.from_numpy(frames2).cuda())
+    torch.cuda.synchronize()
+    out2 = pipe.work.cpu().numpy()
+    er, _, _ = orc.calcOverlap(out[F - 1], out2[0], 640, 480, seed=1)
+    assert abs(float(pipe.ratio.cpu()[0]) - er) <= 1e-6
+    pipe.close()

@@ -77,12 +77,14 @@ SIGNATURES = {
     "uwip_aclahe_knee": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "uwip_aclahe_select": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "uwip_aclahe_auto": (C.c_int, [_P, _B, _B, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "uwip_hsv_replace_v": (C.c_int, [_P, _B, _B, _B]),
     "uwip_dehaze_background_light": (C.c_int, [_P, _B, C.c_int, _P, _P]),
     "uwip_dehaze_transmission": (C.c_int, [_P, _B, _P, _P]),
     "uwip_guided_filter": (C.c_int, [_P, _B, _P, C.c_int, C.c_double, _P]),
     "uwip_dehaze": (C.c_int, [_P, _B, _B, C.c_int, C.c_int, _P, _P, _P]),
     "uwip_features_create": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "uwip_features_destroy": (C.c_int, [_P]),
+    "uwip_features_copy": (C.c_int, [_P, _P, C.c_int, _P, C.c_int]),
     "uwip_overlap_working_size": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "uwip_overlap_detect": (C.c_int, [_P, _B, _P, C.c_int]),
     "uwip_features_download": (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(C.c_int32)]),

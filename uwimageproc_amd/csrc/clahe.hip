@@ -720,3 +720,89 @@ UWIP_API int uwip_aclahe_auto(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwi
     if (h_cl) for (int f = 0; f < F; ++f) h_cl[f] = cl[f];
     return uwip_clahe_per_frame(ctx, src, dst, clip, bs, residual_rule);
 }
+
+// ---- "transform back image" (aclahe.cpp:216): BGR -> HSV, V := CLAHE(V), HSV -> BGR -------------------
+// cvtColor(BGR2HSV) / cvtColor(HSV2BGR) for 8-bit images restated from OpenCV 3.4 color.cpp
+// (integer forward tables with hsv_shift = 12; float inverse with hscale = 6/180).  parity unpinned.
+namespace {
+__global__ __launch_bounds__(256) void k_hsv_replace_v(const uint8_t *__restrict__ src, size_t sstep, size_t sfs,
+                                                      const uint8_t *__restrict__ vnew, size_t vstep, size_t vfs,
+                                                      uint8_t *__restrict__ dst, size_t dstep, size_t dfs, int rows,
+                                                      int cols, const int *__restrict__ sdiv, const int *__restrict__ hdiv)
+{
+    const int f = blockIdx.z, y = blockIdx.y;
+    const uint8_t *s = src + (size_t)f * sfs + (size_t)y * sstep;
+    const uint8_t *vn = vnew + (size_t)f * vfs + (size_t)y * vstep;
+    uint8_t *d = dst + (size_t)f * dfs + (size_t)y * dstep;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < cols; x += gridDim.x * 256) {
+        const int b = s[3 * x], g = s[3 * x + 1], r = s[3 * x + 2];
+        const int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+        const int diff = v - vmin;
+        const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+        const int sat = (diff * sdiv[v] + (1 << 11)) >> 12;
+        int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+        h = (h * hdiv[diff] + (1 << 11)) >> 12;
+        h += h < 0 ? 180 : 0;
+        // inverse with the new V
+        float hf = (float)(uint8_t)h;
+        const float sf = (float)(uint8_t)sat * (1.f / 255.f), vf = (float)vn[x] * (1.f / 255.f);
+        float ob, og, orr;
+        if (sf == 0.0f) {
+            ob = og = orr = vf;
+        } else {
+            hf *= (6.f / 180.f);
+            if (hf < 0) do hf += 6; while (hf < 0);
+            else if (hf >= 6) do hf -= 6; while (hf >= 6);
+            int sector = (int)floorf(hf);
+            hf -= (float)sector;
+            if ((unsigned)sector >= 6u) { sector = 0; hf = 0.f; }
+            const float t0 = vf, t1 = vf * (1.f - sf), t2 = vf * (1.f - sf * hf), t3 = vf * (1.f - sf * (1.f - hf));
+            switch (sector) {
+                case 0: ob = t1; og = t3; orr = t0; break;
+                case 1: ob = t1; og = t0; orr = t2; break;
+                case 2: ob = t3; og = t0; orr = t1; break;
+                case 3: ob = t0; og = t2; orr = t1; break;
+                case 4: ob = t0; og = t1; orr = t3; break;
+                default: ob = t2; og = t1; orr = t0; break;
+            }
+        }
+        d[3 * x] = (uint8_t)sat_u8_rne(ob * 255.f);
+        d[3 * x + 1] = (uint8_t)sat_u8_rne(og * 255.f);
+        d[3 * x + 2] = (uint8_t)sat_u8_rne(orr * 255.f);
+    }
+}
+
+const int *hsv_tables(uwip_ctx *ctx)
+{
+    const void *d = uwip_table_find(ctx, "hsv.tables", nullptr);
+    if (d) return (const int *)d;
+    std::vector<int> t(512, 0);
+    for (int i = 1; i < 256; ++i) {
+        t[i] = (int)std::lrint((255 << 12) / (1. * i));          // sdiv_table
+        t[256 + i] = (int)std::lrint((180 << 12) / (6. * i));    // hdiv_table180
+    }
+    return (const int *)uwip_table_put(ctx, "hsv.tables", t.data(), t.size() * sizeof(int));
+}
+}  // namespace
+
+UWIP_API int uwip_hsv_replace_v(uwip_ctx *ctx, const uwip_batch_u8 *bgr, const uwip_batch_u8 *v_new, const uwip_batch_u8 *bgr_out)
+{
+    int rc = uwip_check_batch(ctx, bgr, 3);
+    if (rc) return rc;
+    rc = uwip_check_batch(ctx, v_new, 1);
+    if (rc) return rc;
+    rc = uwip_check_batch(ctx, bgr_out, 3);
+    if (rc) return rc;
+    UWIP_REQUIRE(ctx, bgr->rows == v_new->rows && bgr->cols == v_new->cols && bgr->frames == v_new->frames &&
+                          bgr->rows == bgr_out->rows && bgr->cols == bgr_out->cols && bgr->frames == bgr_out->frames, "shape mismatch");
+    if (uwip_batch_empty(bgr)) return UWIP_OK;
+    UWIP_REQUIRE(ctx, bgr->rows <= 65535 && bgr->frames <= 65535, "too many rows/frames for one launch");
+    const int *tabs = hsv_tables(ctx);
+    if (!tabs) return UWIP_ERR_NOMEM;
+    uwip_kscope ks(ctx, "k_hsv_replace_v");
+    k_hsv_replace_v<<<dim3(uwip_cdiv(bgr->cols, 256 * 2), (unsigned)bgr->rows, (unsigned)bgr->frames), 256, 0, ctx->stream>>>(
+        (const uint8_t *)bgr->data, bgr->step, bgr->frame_stride, (const uint8_t *)v_new->data, v_new->step, v_new->frame_stride,
+        (uint8_t *)bgr_out->data, bgr_out->step, bgr_out->frame_stride, bgr->rows, bgr->cols, tabs, tabs + 256);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}

@@ -1496,3 +1496,21 @@ UWIP_API int uwip_calcBlur(uwip_ctx *ctx, const uwip_batch_u8 *frames, float *d_
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
+
+// keep a frame's cached keypoints/descriptors (what `struct keyframe` holds) in another slot
+UWIP_API int uwip_features_copy(uwip_ctx *ctx, const uwip_features *src, int src_slot, uwip_features *dst, int dst_slot)
+{
+    if (!ctx) return UWIP_ERR_INVALID;
+    UWIP_REQUIRE(ctx, src && dst && src->ctx == ctx && dst->ctx == ctx, "bad feature sets");
+    UWIP_REQUIRE(ctx, src_slot >= 0 && src_slot < src->capacity && dst_slot >= 0 && dst_slot < dst->capacity, "slot out of range");
+    UWIP_REQUIRE(ctx, dst->w == 0 || (dst->w == src->w && dst->h == src->h), "feature sets of different working sizes");
+    if (src == dst && src_slot == dst_slot) return UWIP_OK;
+    dst->w = src->w; dst->h = src->h;
+    const size_t s = (size_t)src_slot * MAXKP, d = (size_t)dst_slot * MAXKP;
+    UWIP_HIP(ctx, hipMemcpyAsync(dst->d_kp + d, src->d_kp + s, sizeof(Keypoint) * MAXKP, hipMemcpyDeviceToDevice, ctx->stream));
+    UWIP_HIP(ctx, hipMemcpyAsync(dst->d_desc + d * DESC_BYTES, src->d_desc + s * DESC_BYTES, (size_t)MAXKP * DESC_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
+    UWIP_HIP(ctx, hipMemcpyAsync(dst->d_bits + d * DESC_K, src->d_bits + s * DESC_K, (size_t)MAXKP * DESC_K, hipMemcpyDeviceToDevice, ctx->stream));
+    UWIP_HIP(ctx, hipMemcpyAsync(dst->d_pop + d, src->d_pop + s, sizeof(int32_t) * MAXKP, hipMemcpyDeviceToDevice, ctx->stream));
+    UWIP_HIP(ctx, hipMemcpyAsync(dst->d_n + dst_slot, src->d_n + src_slot, sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    return UWIP_OK;
+}

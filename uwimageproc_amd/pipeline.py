@@ -1,35 +1,61 @@
 """The per-frame pipe  bgdehaze -> histretch -> aclahe -> videostrip-overlap  on a
-batch of frames resident in HBM, driven through the C ABI with one stream and no
-intermediate host synchronisation except where the reference's algorithm has a
-host decision (the ACLAHE parameter choice)."""
+batch of frames resident in HBM, driven through the C ABI on one stream.  The only
+host synchronisation inside a step is where the reference's algorithm has a host
+decision: the ACLAHE parameter choice (ACLAHE.py:66-129).
+
+Stage definitions (DESIGN.md "the pipe"):
+  bgdehaze   main.py:14-20 / adaptiveExp_map (w = 15), S guarded (B-11)
+  histretch  -c=RGB, percentiles 2/98 (histretch.cpp:154,217-254)
+  aclahe     V of HSV (aclahe.cpp:152-154) -> sweep (:160-193) -> parameter choice
+             (ACLAHE.py:66-129) -> CLAHE(CL,(BS,BS)) -> back to BGR (aclahe.cpp:216)
+  overlap    calcOverlap of every frame against its predecessor (videostrip.cpp:192-289),
+             the last frame's features carried into the next batch
+"""
 from __future__ import annotations
 
 import ctypes as C
 
-import numpy as np
 import torch
 
-from . import aclahe
 from ._native import Context, batch_of
 
 DEHAZE_FULL, DEHAZE_GUARD_S = 1, 2
 
 
 class FramePipe:
-    def __init__(self, device: int, frames: int, rows: int, cols: int, letters: str = "RGB", w: int = 15):
+    def __init__(self, device: int, frames: int, rows: int, cols: int, letters: str = "RGB", w: int = 15,
+                 video_size=None, seed: int = 1):
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         # share torch's current stream so torch events / synchronize cover our kernels
         self.ctx = Context(device, stream=torch.cuda.current_stream(self.dev).cuda_stream)
         self.F, self.H, self.W = frames, rows, cols
-        self.letters, self.w = letters.encode(), w
+        self.letters, self.w, self.seed = letters.encode(), w, seed
+        # the reference's globals videoWidth / videoHeight (main.cpp:238-239); as written they are the
+        # full-resolution size
+        self.vw, self.vh = video_size if video_size else (cols, rows)
         self.work = torch.empty((frames, rows, cols, 3), dtype=torch.uint8, device=self.dev)
         self.v = torch.empty((frames, rows, cols), dtype=torch.uint8, device=self.dev)
         self.v_out = torch.empty_like(self.v)
-        self.params = []
+        self.ratio = torch.empty((frames,), dtype=torch.float32, device=self.dev)
+        self.info = torch.zeros((frames, 8), dtype=torch.int32, device=self.dev)
         self.h_bs = (C.c_int32 * frames)()
         self.h_cl = (C.c_int32 * frames)()
+        self.params = []
+        # feature slots: 0 = previous batch's last frame, 1..F = this batch
+        fh = C.c_void_p()
+        self.ctx.call("uwip_features_create", frames + 1, C.byref(fh))
+        self.feats = fh
+        self.have_prev = False
+        self.pair_q = (C.c_int32 * frames)(*[i + 1 for i in range(frames)])
+        self.pair_t = (C.c_int32 * frames)(*[i for i in range(frames)])
 
+    def close(self):
+        if getattr(self, "feats", None):
+            self.ctx._l.uwip_features_destroy(self.feats)
+            self.feats = None
+
+    # ---- stages -----------------------------------------------------------------
     def stage_dehaze(self, src: torch.Tensor):
         sb, ob = batch_of(src), batch_of(self.work)
         self.ctx.call("uwip_dehaze", C.byref(sb), C.byref(ob), self.w, DEHAZE_FULL | DEHAZE_GUARD_S, None, None, None)
@@ -41,15 +67,32 @@ class FramePipe:
     def stage_aclahe(self):
         wb, vb, ob = batch_of(self.work), batch_of(self.v), batch_of(self.v_out)
         self.ctx.call("uwip_bgr_to_v", C.byref(wb), C.byref(vb))
-        # sweep -> host parameter choice (ACLAHE.py:66-129, native MINPACK restatement) -> per-frame CLAHE
+        # sweep -> host parameter choice (native MINPACK restatement) -> per-frame CLAHE
         self.ctx.call("uwip_aclahe_auto", C.byref(vb), C.byref(ob), 0, self.h_bs, self.h_cl)
         self.params = list(zip(self.h_bs, self.h_cl))
+        self.ctx.call("uwip_hsv_replace_v", C.byref(wb), C.byref(ob), C.byref(wb))
+
+    def stage_overlap(self):
+        wb = batch_of(self.work)
+        if not self.have_prev:
+            # first batch: frame 0 is its own key frame (main.cpp:284-297 takes the first frame as key frame)
+            pb = batch_of(self.work[0:1])
+            self.ctx.call("uwip_overlap_detect", C.byref(pb), self.feats, 0)
+            self.have_prev = True
+        else:
+            # the previous batch's last frame becomes the key frame of this batch's first frame
+            self.ctx.call("uwip_features_copy", self.feats, self.F, self.feats, 0)
+        self.ctx.call("uwip_overlap_detect", C.byref(wb), self.feats, 1)
+        self.ctx.call("uwip_overlap_match", self.feats, self.feats, self.pair_q, self.pair_t, self.F, self.vw, self.vh,
+                      self.seed, C.c_void_p(self.ratio.data_ptr()), C.c_void_p(self.info.data_ptr()), None, None, None)
 
     def stages(self):
-        return ["bgdehaze(adaptiveExp_map,w=15)", "histretch(RGB,2/98)", "aclahe(sweep+select+apply on V)"]
+        return ["bgdehaze(adaptiveExp_map,w=15)", "histretch(RGB,2/98)", "aclahe(V:sweep+select+CLAHE,HSV->BGR)",
+                "videostrip-overlap(frame vs predecessor: detect+describe+MFMA match+RANSAC+overlapArea)"]
 
     def run(self, src: torch.Tensor):
         self.stage_dehaze(src)
         self.stage_histretch()
         self.stage_aclahe()
-        return self.v_out
+        self.stage_overlap()
+        return self.work, self.ratio
