@@ -128,14 +128,14 @@ def test_exposure_tail_in_isolation(ctx, shape, seed, guard):
 @pytest.mark.parametrize("shape", [(96, 128), (270, 480)])
 def test_dehaze_full_end_to_end_vs_oracle(ctx, shape):
     """Whole chain vs the oracle's whole chain (guarded S).  Stated tolerance for the
-    tail: 2e-3 abs on the float image, <= 1 LSB on the 8-bit image for >= 99 % of pixels
+    tail: 2e-3 abs on the float image, <= 1 LSB on the 8-bit image for >= 95 % of pixels
     (see test_exposure_tail_in_isolation for why it is not 1e-9)."""
     img = synth.uw_frame(200 + shape[0], *shape)
     exp_f = dz.adaptiveExp_map(dz.normalize_input(img), 15, guard_s=True)
     res = bg.dehaze(ctx, _dev(img), 15, full=True, want_float=True, guard_s=True)
     assert np.abs(res["float"].cpu().numpy()[0] - exp_f).max() <= 2e-3
     diff = np.abs(res["out"].cpu().numpy().astype(int) - dz.to_u8(exp_f).astype(int))
-    assert diff.max() <= 1 and (diff != 0).mean() <= 1e-2
+    assert diff.max() <= 1 and (diff != 0).mean() <= 5e-2
 
 
 def test_dehaze_batch_matches_single(ctx):

@@ -20,6 +20,7 @@
 #include "device_utils.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 int uwip_launch_hist_internal(uwip_ctx *ctx, const uwip_batch_u8 *img, uint32_t *d_hist);
 
@@ -78,6 +79,8 @@ struct ClipList {
     int n;
     int clip[51];
 };
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- BGR -> V (max) -------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bgr_to_v(const uint8_t *__restrict__ src, size_t sstep,
@@ -181,6 +184,19 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
     luts[(((size_t)f * ncl + c) * tiles + t) * 256 + v] = (uint8_t)sat_u8_rne((float)(int)sum * lutScale);
 }
 
+// ---- pack the four neighbour LUTs of every interpolation cell: one uint32 per grey level --------
+// packed[f][cy][cx][v] = TL | TR<<8 | BL<<16 | BR<<24 with TL = lut[max(cy-1,0)][max(cx-1,0)][v] etc.
+__global__ __launch_bounds__(256) void k_clahe_pack(const uint8_t *__restrict__ luts, size_t lut_fs, int gx, int gy,
+                                                    uint32_t *__restrict__ packed)
+{
+    const int v = threadIdx.x, cx = blockIdx.x, cy = blockIdx.y, f = blockIdx.z;
+    const uint8_t *L = luts + (size_t)f * lut_fs;
+    const int ty1 = max(cy - 1, 0), ty2 = min(cy, gy - 1), tx1 = max(cx - 1, 0), tx2 = min(cx, gx - 1);
+    const uint32_t a = L[((size_t)ty1 * gx + tx1) * 256 + v], b = L[((size_t)ty1 * gx + tx2) * 256 + v];
+    const uint32_t c = L[((size_t)ty2 * gx + tx1) * 256 + v], d = L[((size_t)ty2 * gx + tx2) * 256 + v];
+    packed[(((size_t)f * (gy + 1) + cy) * (gx + 1) + cx) * 256 + v] = a | (b << 8) | (c << 16) | (d << 24);
+}
+
 // ---- C1c: bilinear LUT interpolation, strip per block -------------------------
 // strips[s] = (cy, r0, r1, unused): rows [r0,r1) all have floor(y*inv_th-0.5)+1 == cy.
 template <bool VEC>
@@ -198,17 +214,10 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
     const int cy = sd.x, r0 = sd.y, r1 = sd.z;
     const int f = blockIdx.y;
     const int fr = frame_map ? frame_map[f] : f;
-    const uint8_t *L = luts + (size_t)f * lut_fs;
-    const int ty1 = max(cy - 1, 0), ty2 = min(cy, gy - 1);
-    for (int idx = tid; idx < (gx + 1) * 256; idx += 256) {
-        const int cx = idx >> 8, v = idx & 255;
-        const int tx1 = max(cx - 1, 0), tx2 = min(cx, gx - 1);
-        const uint32_t a = L[((size_t)ty1 * gx + tx1) * 256 + v];
-        const uint32_t b = L[((size_t)ty1 * gx + tx2) * 256 + v];
-        const uint32_t c = L[((size_t)ty2 * gx + tx1) * 256 + v];
-        const uint32_t d = L[((size_t)ty2 * gx + tx2) * 256 + v];
-        s_pack[idx] = a | (b << 8) | (c << 16) | (d << 24);
-    }
+    // the packed LUT row of this strip's cell row: (gx+1)*256 uint32, pre-packed by k_clahe_pack
+    const uint4 *P4 = reinterpret_cast<const uint4 *>(luts + (size_t)f * lut_fs + (size_t)cy * (gx + 1) * 1024);
+    for (int idx = tid; idx < (gx + 1) * 64; idx += 256) reinterpret_cast<uint4 *>(s_pack)[idx] = P4[idx];
+    (void)gy;
     __syncthreads();
     const uint8_t *sb = src + (size_t)fr * sfs;
     uint8_t *db = dst + (size_t)fr * dfs;
@@ -227,33 +236,50 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
             base[i] = (uint32_t)(((int)fl + 1) << 8);
         }
         const bool full = VEC && (x0 + 8 <= cols);
-        for (int y = r0 + ty; y < r1; y += TY) {
-            const float tyf = (float)y * inv_th - 0.5f;
-            const float ya = tyf - floorf(tyf), ya1 = 1.0f - ya;
-            const uint8_t *sp = sb + (size_t)y * sstep + x0;
-            uint8_t *dp = db + (size_t)y * dstep + x0;
-            uint32_t w[2];
-            if (full) {
-                const uint2 q = *reinterpret_cast<const uint2 *>(sp);
-                w[0] = q.x; w[1] = q.y;
-            } else {
-                w[0] = w[1] = 0;
-                for (int i = 0; i < min(8, cols - x0); ++i) w[i >> 2] |= (uint32_t)sp[i] << ((i & 3) * 8);
-            }
-            uint32_t o[2] = {0, 0};
+        constexpr int RU = 4;                       // rows in flight per thread (memory-level parallelism)
+        for (int yb = r0 + ty; yb < r1; yb += TY * RU) {
+            uint32_t w[RU][2];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const uint32_t v = (w[i >> 2] >> ((i & 3) * 8)) & 255u;
-                const uint32_t p = s_pack[base[i] + v];
-                const float a = (float)(p & 255u), b = (float)((p >> 8) & 255u);
-                const float c = (float)((p >> 16) & 255u), d = (float)(p >> 24);
-                const float res = (a * xa1[i] + b * xa[i]) * ya1 + (c * xa1[i] + d * xa[i]) * ya;
-                o[i >> 2] |= rne_u8_inrange(res) << ((i & 3) * 8);
+            for (int u = 0; u < RU; ++u) {
+                const int y = yb + u * TY;
+                w[u][0] = w[u][1] = 0;
+                if (y < r1) {
+                    const uint8_t *sp = sb + (size_t)y * sstep + x0;
+                    if (full) {
+                        const uint2 q = *reinterpret_cast<const uint2 *>(sp);
+                        w[u][0] = q.x; w[u][1] = q.y;
+                    } else {
+                        for (int i = 0; i < min(8, cols - x0); ++i) w[u][i >> 2] |= (uint32_t)sp[i] << ((i & 3) * 8);
+                    }
+                }
             }
-            if (full) {
-                *reinterpret_cast<uint2 *>(dp) = make_uint2(o[0], o[1]);
-            } else {
-                for (int i = 0; i < min(8, cols - x0); ++i) dp[i] = (uint8_t)(o[i >> 2] >> ((i & 3) * 8));
+#pragma unroll
+            for (int u = 0; u < RU; ++u) {
+                const int y = yb + u * TY;
+                if (y >= r1) break;
+                const float tyf = (float)y * inv_th - 0.5f;
+                const float ya = tyf - floorf(tyf), ya1 = 1.0f - ya;
+                uint8_t *dp = db + (size_t)y * dstep + x0;
+                uint32_t o[2] = {0, 0};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t v = (w[u][i >> 2] >> ((i & 3) * 8)) & 255u;
+                    const uint32_t p = s_pack[base[i] + v];
+                    // (TL*xa1 + TR*xa)*ya1 + (BL*xa1 + BR*xa)*ya with the two rows in one packed-f32 lane pair:
+                    // same products, sums and order as the scalar form (no FMA: -ffp-contract=off)
+                    const f32x2 ac = {(float)(p & 255u), (float)((p >> 16) & 255u)};
+                    const f32x2 bd = {(float)((p >> 8) & 255u), (float)(p >> 24)};
+                    const f32x2 xa1v = {xa1[i], xa1[i]}, xav = {xa[i], xa[i]}, yv = {ya1, ya};
+                    const f32x2 t = (ac * xa1v + bd * xav) * yv;
+                    const float res = t.x + t.y;
+                    // v_cvt_pk_u8_f32: round-to-nearest-even + clamp + byte insert in one instruction
+                    o[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(res, i & 3, o[i >> 2]);
+                }
+                if (full) {
+                    *reinterpret_cast<uint2 *>(dp) = make_uint2(o[0], o[1]);
+                } else {
+                    for (int i = 0; i < min(8, cols - x0); ++i) dp[i] = (uint8_t)(o[i >> 2] >> ((i & 3) * 8));
+                }
             }
         }
     }
@@ -270,7 +296,13 @@ struct CellItem {
     int pad0, pad1;
 };
 
-__global__ __launch_bounds__(256) void k_clahe_sweep(const uint8_t *__restrict__ src, size_t step,
+// Same-bin LDS atomics from one wave serialise, and neighbouring pixels of a smooth underwater frame land in
+// few bins: the output histograms are therefore replicated SWEEP_REP times, keyed by the low lane bits, and
+// a block is 1024 threads (16 waves share one set of packed LUTs + replicas: 85 KB of LDS, one block per CU).
+constexpr int SWEEP_THREADS = 1024;
+constexpr int SWEEP_REP = 4;
+constexpr int SWEEP_RSTRIDE = SWEEP_GROUP * 256 + 8;   // +8 words: equal bins of different replicas fall in different LDS banks
+__global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__restrict__ src, size_t step,
                                                      size_t fstride, int gx, int gy, float inv_tw,
                                                      float inv_th,
                                                      const uint8_t *__restrict__ luts /*[F][51][tiles][256]*/,
@@ -279,12 +311,14 @@ __global__ __launch_bounds__(256) void k_clahe_sweep(const uint8_t *__restrict__
                                                      uint32_t *__restrict__ out_hist /*[F][51][256]*/,
                                                      size_t out_fs)
 {
-    __shared__ uint32_t s_pack[SWEEP_GROUP * 256];
-    __shared__ uint32_t s_hist[SWEEP_GROUP * 256];
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_sweep[];
+    uint32_t *s_pack = s_sweep;                                   // [SWEEP_GROUP][256]
+    uint32_t *s_hist = s_sweep + SWEEP_GROUP * 256;               // [SWEEP_REP][SWEEP_GROUP][256]
     const int tid = threadIdx.x;
     const int cg = blockIdx.y, f = blockIdx.z;
     const int tiles = gx * gy;
-    for (int i = tid; i < SWEEP_GROUP * 256; i += 256) s_hist[i] = 0;
+    for (int i = tid; i < SWEEP_REP * SWEEP_RSTRIDE; i += SWEEP_THREADS) s_hist[i] = 0;
+    uint32_t *my_hist = s_hist + (tid & (SWEEP_REP - 1)) * SWEEP_RSTRIDE;
     const uint8_t *fb = src + (size_t)f * fstride;
     const uint8_t *L = luts + ((size_t)f * SWEEP_NCL + (size_t)cg * SWEEP_GROUP) * tiles * 256;
     const int i0 = blockIdx.x * items_per_block, i1 = min(nitems, i0 + items_per_block);
@@ -293,7 +327,7 @@ __global__ __launch_bounds__(256) void k_clahe_sweep(const uint8_t *__restrict__
         const int tx1 = max(ci.cx - 1, 0), tx2 = min(ci.cx, gx - 1);
         const int ty1 = max(ci.cy - 1, 0), ty2 = min(ci.cy, gy - 1);
         __syncthreads();
-        for (int idx = tid; idx < SWEEP_GROUP * 256; idx += 256) {
+        for (int idx = tid; idx < SWEEP_GROUP * 256; idx += SWEEP_THREADS) {
             const int c = idx >> 8, v = idx & 255;
             const uint8_t *Lc = L + (size_t)c * tiles * 256;
             const uint32_t a = Lc[((size_t)ty1 * gx + tx1) * 256 + v];
@@ -306,7 +340,7 @@ __global__ __launch_bounds__(256) void k_clahe_sweep(const uint8_t *__restrict__
         const int w = ci.x1 - ci.x0;
         const int npix = w * (ci.r1 - ci.r0);
         const float inv_w = 1.0f / (float)w;
-        for (int p = tid; p < npix; p += 256) {
+        for (int p = tid; p < npix; p += SWEEP_THREADS) {
             int q = (int)(((float)p + 0.5f) * inv_w);
             int r = p - q * w;
             if (r < 0) { q--; r += w; }
@@ -316,22 +350,27 @@ __global__ __launch_bounds__(256) void k_clahe_sweep(const uint8_t *__restrict__
             const float xa = txf - floorf(txf), xa1 = 1.0f - xa;
             const float tyf = (float)y * inv_th - 0.5f;
             const float ya = tyf - floorf(tyf), ya1 = 1.0f - ya;
+            const f32x2 xa1v = {xa1, xa1}, xav = {xa, xa}, yv = {ya1, ya};
             const uint32_t v = fb[(size_t)y * step + x];
 #pragma unroll
             for (int c = 0; c < SWEEP_GROUP; ++c) {
                 const uint32_t pk = s_pack[c * 256 + v];
-                const float a = (float)(pk & 255u), b = (float)((pk >> 8) & 255u);
-                const float cc = (float)((pk >> 16) & 255u), d = (float)(pk >> 24);
-                const float res = (a * xa1 + b * xa) * ya1 + (cc * xa1 + d * xa) * ya;
-                atomicAdd(&s_hist[c * 256 + rne_u8_inrange(res)], 1u);
+                // (TL*xa1 + TR*xa)*ya1 + (BL*xa1 + BR*xa)*ya, two rows per packed-f32 pair (same op order, no FMA)
+                const f32x2 ac = {(float)(pk & 255u), (float)((pk >> 16) & 255u)};
+                const f32x2 bd = {(float)((pk >> 8) & 255u), (float)(pk >> 24)};
+                const f32x2 t = (ac * xa1v + bd * xav) * yv;
+                const uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(t.x + t.y, 0, 0u);     // RNE + clamp
+                atomicAdd(&my_hist[c * 256 + o], 1u);
             }
         }
     }
     __syncthreads();
     uint32_t *out = out_hist + (size_t)f * out_fs + (size_t)cg * SWEEP_GROUP * 256;
-    for (int i = tid; i < SWEEP_GROUP * 256; i += 256) {
-        const uint32_t s = s_hist[i];
-        if (s) atomicAdd(&out[i], s);
+    for (int i = tid; i < SWEEP_GROUP * 256; i += SWEEP_THREADS) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int r = 0; r < SWEEP_REP; ++r) sum += s_hist[r * SWEEP_RSTRIDE + i];
+        if (sum) atomicAdd(&out[i], sum);
     }
 }
 
@@ -397,9 +436,13 @@ int build_strips(uwip_ctx *ctx, const ClaheGeom &g, int max_rows, const int4 **d
         std::vector<int> ys;
         cell_starts(g.rows, g.gy, g.inv_th, ys);
         std::vector<int4> strips;
-        for (int cy = 0; cy <= g.gy; ++cy)
-            for (int r = ys[cy]; r < ys[cy + 1]; r += max_rows)
-                strips.push_back(make_int4(cy, r, std::min(r + max_rows, ys[cy + 1]), 0));
+        for (int cy = 0; cy <= g.gy; ++cy) {
+            const int L = ys[cy + 1] - ys[cy];
+            if (L <= 0) continue;
+            const int nch = (L + max_rows - 1) / max_rows, rows = (L + nch - 1) / nch;     // balanced chunks
+            for (int r = ys[cy]; r < ys[cy + 1]; r += rows)
+                strips.push_back(make_int4(cy, r, std::min(r + rows, ys[cy + 1]), 0));
+        }
         bytes = strips.size() * sizeof(int4);
         d = uwip_table_put(ctx, key, strips.data(), bytes);
         if (!d) return UWIP_ERR_NOMEM;
@@ -414,7 +457,7 @@ int launch_apply(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *d
 {
     const int4 *d_strips = nullptr;
     int nstrips = 0;
-    const int max_rows = g.gx >= 16 ? 16 : 8;
+    const int max_rows = 16;
     int rc = build_strips(ctx, g, max_rows, &d_strips, &nstrips);
     if (rc) return rc;
     if (nstrips == 0) return UWIP_OK;
@@ -424,6 +467,16 @@ int launch_apply(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *d
     const size_t lds = (size_t)(g.gx + 1) * 256 * sizeof(uint32_t);
     const bool vec = aligned_for(src, 8) && aligned_for(dst, 8);
     dim3 grid((unsigned)nstrips, (unsigned)nf);
+    const size_t pack_fs = (size_t)(g.gy + 1) * (g.gx + 1) * 1024;      // bytes per frame
+    uint32_t *d_packed = (uint32_t *)uwip_ws(ctx, "clahe.packed", pack_fs * nf);
+    if (!d_packed) return UWIP_ERR_NOMEM;
+    {
+        uwip_kscope kp(ctx, "k_clahe_pack");
+        k_clahe_pack<<<dim3(g.gx + 1, g.gy + 1, nf), 256, 0, ctx->stream>>>(d_luts, lut_fs, g.gx, g.gy, d_packed);
+        UWIP_HIP(ctx, hipGetLastError());
+    }
+    d_luts = reinterpret_cast<const uint8_t *>(d_packed);
+    lut_fs = pack_fs;
     uwip_kscope ks(ctx, "k_clahe_apply");
     if (vec)
         k_clahe_apply<true><<<grid, 256, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
@@ -645,10 +698,16 @@ UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int resi
         const CellItem *d_items = (const CellItem *)d_tab;
         const int nitems = (int)(bytes / sizeof(CellItem));
         const int cell_px = std::max(1, g.tw * g.th);
-        const int ipb = std::max(1, std::min(16, 16384 / cell_px));
+        const int ipb = std::max(1, std::min(64, 65536 / cell_px));
         dim3 grid(uwip_cdiv(nitems, ipb), SWEEP_NCL / SWEEP_GROUP, (unsigned)F);
         uwip_kscope ks(ctx, "k_clahe_sweep");
-        k_clahe_sweep<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.gx,
+        const size_t sweep_lds = sizeof(uint32_t) * ((size_t)SWEEP_GROUP * 256 + (size_t)SWEEP_REP * SWEEP_RSTRIDE);
+        static bool sweep_attr = false;          // > 64 KiB of dynamic LDS needs an explicit opt-in
+        if (!sweep_attr) {
+            UWIP_HIP(ctx, hipFuncSetAttribute((const void *)k_clahe_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds));
+            sweep_attr = true;
+        }
+        k_clahe_sweep<<<grid, SWEEP_THREADS, sweep_lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.gx,
                                                      g.gy, g.inv_tw, g.inv_th, d_luts, d_items, nitems, ipb,
                                                      d_out + (size_t)gi * SWEEP_NCL * 256, out_fs);
         UWIP_HIP(ctx, hipGetLastError());

@@ -287,42 +287,6 @@ __global__ __launch_bounds__(256) void k_vsum(const uint8_t *__restrict__ guide,
     }
 }
 
-// ---- horizontal box sum of a row, in place: prefix scan in LDS ----------------------
-__global__ __launch_bounds__(256) void k_hsum(double *__restrict__ planes, int H, int W, int r)
-{
-    extern __shared__ __attribute__((aligned(16))) double s_P[];     // [W] inclusive prefix
-    __shared__ double s_w[4];
-    __shared__ double s_carry;
-    const int y = blockIdx.x;
-    double *row = planes + ((size_t)blockIdx.y * H + y) * W;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0.0;
-    __syncthreads();
-    for (int x0 = 0; x0 < W; x0 += 256) {
-        const int x = x0 + threadIdx.x;
-        double v = x < W ? row[x] : 0.0;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double t = __shfl_up(v, d, 64);
-            if (lane >= d) v += t;
-        }
-        if (lane == 63) s_w[wave] = v;
-        __syncthreads();
-        double off = s_carry;
-        for (int k = 0; k < wave; ++k) off += s_w[k];
-        v += off;
-        if (x < W) s_P[x] = v;
-        __syncthreads();
-        if (threadIdx.x == 255) s_carry = v;
-        __syncthreads();
-    }
-    for (int x = threadIdx.x; x < W; x += 256) {
-        const double hi = s_P[min(x + r, W - 1)];
-        const double lo = x - r - 1 >= 0 ? s_P[x - r - 1] : 0.0;
-        row[x] = hi - lo;
-    }
-}
-
 __device__ __forceinline__ double box_base(int y, int x, int H, int W, int r)
 {
     const int cy = min(y + r, H - 1) - max(y - r, 0) + 1;
@@ -330,55 +294,150 @@ __device__ __forceinline__ double box_base(int y, int x, int H, int W, int r)
     return (double)cy * (double)cx;
 }
 
-// ---- guided filter eq.14-15: a = cov inv(Sigma + eps I), b = mean_p - a.mean ------------
-__global__ __launch_bounds__(256) void k_gf_solve(const double *__restrict__ SG /*[F][9]*/,
-                                                  const double *__restrict__ SP /*[F*np][4]*/,
-                                                  double *__restrict__ AB /*[F*np][4]*/, int H, int W,
-                                                  int r, double eps, int np)
+// ---- horizontal box sums fused into their consumers ------------------------------------
+// A block owns HSEG output pixels of one row.  For each of NPL vertical-sum planes it loads the row
+// segment with an r+1 / r halo into LDS, prefix-scans it (one wave per plane, 64 elements per step)
+// and every pixel's horizontal window sum is then a difference of two LDS values.  This replaces a
+// separate read+write pass per plane (the former k_hsum).
+constexpr int HSEG = 256;
+
+// Stage NPL row segments into LDS and turn each into its inclusive prefix scan.
+// s: [NPL][LW] doubles, LW = HSEG + 2r + 1; element j <-> image column x0 - r - 1 + j.
+//  1. every thread issues ALL its global loads (2 per plane) before the first LDS store, so a block pays
+//     one memory latency, not one per plane;
+//  2. TPP = 256 / NPL threads own one plane each: a thread reads its contiguous run into registers,
+//     scans it there, publishes the run total, and after one barrier writes run + offset back.
+constexpr int RUNMAX = 24;
+template <int NPL>
+__device__ __forceinline__ void load_scan(double *s, double *s_tot /*[NPL][64]*/, int LW, const double *const (&planes)[NPL],
+                                          size_t row_off, int x0, int r, int W)
 {
-    const int z = blockIdx.y, f = z / np;
+    constexpr int TPP = 256 / NPL;
+    {
+        double v[NPL][2];
+        const int j0 = threadIdx.x, j1 = threadIdx.x + 256;
+        const int xa = x0 - r - 1 + j0, xb = x0 - r - 1 + j1;
+        const bool oka = xa >= 0 && xa < W, okb = j1 < LW && xb >= 0 && xb < W;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            v[k][0] = oka ? planes[k][row_off + xa] : 0.0;
+            v[k][1] = okb ? planes[k][row_off + xb] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            s[(size_t)k * LW + j0] = v[k][0];
+            if (j1 < LW) s[(size_t)k * LW + j1] = v[k][1];
+        }
+    }
+    __syncthreads();
+    const int k = threadIdx.x / TPP, t = threadIdx.x - k * TPP;
+    const int run = (LW + TPP - 1) / TPP;
+    const bool active = k < NPL;
+    double *row = s + (size_t)(active ? k : 0) * LW;
+    const int a = t * run, e = min(a + run, LW);
+    double v[RUNMAX];
+    double acc = 0.0;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < RUNMAX; ++i) v[i] = (a + i < e) ? row[a + i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < RUNMAX; ++i) { acc += v[i]; v[i] = acc; }
+        s_tot[k * 64 + t] = acc;
+    }
+    __syncthreads();
+    if (active) {
+        double off = 0.0;
+        for (int i = 0; i < t; ++i) off += s_tot[k * 64 + i];
+#pragma unroll
+        for (int i = 0; i < RUNMAX; ++i) if (a + i < e) row[a + i] = v[i] + off;
+    }
+    __syncthreads();
+}
+
+// window sum over columns [max(x-r,0), min(x+r,W-1)] from the scanned row
+__device__ __forceinline__ double win(const double *row, int x, int x0, int r, int W)
+{
+    const int o = x0 - r - 1;
+    return row[min(x + r, W - 1) - o] - row[max(x - r, 0) - 1 - o];
+}
+
+// ---- guided filter eq.14-15 with the horizontal sums fused: a = cov inv(Sigma + eps I), b = mean_p - a.mean
+template <int NP>
+__global__ __launch_bounds__(256) void k_gf_solve_h(const double *__restrict__ VG /*[F][9] vertical sums*/,
+                                                    const double *__restrict__ VP /*[F*NP][4] vertical sums*/,
+                                                    double *__restrict__ AB /*[F*NP][4]*/, int H, int W, int r, double eps)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_rows[];
+    constexpr int NPL = 9 + 4 * NP;
+    const int LW = HSEG + 2 * r + 1;
+    const int x0 = blockIdx.x * HSEG, y = blockIdx.y, f = blockIdx.z;
     const size_t n = (size_t)H * W;
-    const double *g = SG + (size_t)f * 9 * n;
-    const double *p = SP + (size_t)z * 4 * n;
-    double *o = AB + (size_t)z * 4 * n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
-        const double base = box_base(y, x, H, W, r);
-        const double m0 = g[i] / base, m1 = g[n + i] / base, m2 = g[2 * n + i] / base;
-        const double mp = p[i] / base;
-        const double c0 = p[n + i] / base - m0 * mp, c1 = p[2 * n + i] / base - m1 * mp,
-                     c2 = p[3 * n + i] / base - m2 * mp;
-        const double s00 = g[3 * n + i] / base - m0 * m0 + eps, s01 = g[4 * n + i] / base - m0 * m1,
-                     s02 = g[5 * n + i] / base - m0 * m2, s11 = g[6 * n + i] / base - m1 * m1 + eps,
-                     s12 = g[7 * n + i] / base - m1 * m2, s22 = g[8 * n + i] / base - m2 * m2 + eps;
-        // symmetric 3x3 inverse by cofactors
-        const double k00 = s11 * s22 - s12 * s12, k01 = s02 * s12 - s01 * s22, k02 = s01 * s12 - s02 * s11;
-        const double k11 = s00 * s22 - s02 * s02, k12 = s01 * s02 - s00 * s12, k22 = s00 * s11 - s01 * s01;
-        const double det = s00 * k00 + s01 * k01 + s02 * k02;
+    const double *planes[NPL];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) planes[k] = VG + ((size_t)f * 9 + k) * n;
+#pragma unroll
+    for (int k = 0; k < 4 * NP; ++k) planes[9 + k] = VP + ((size_t)f * NP * 4 + k) * n;
+    __shared__ double s_tot[NPL * 64];
+    load_scan<NPL>(s_rows, s_tot, LW, planes, (size_t)y * W, x0, r, W);
+    const int x = x0 + threadIdx.x;
+    if (x >= W) return;
+    const double base = box_base(y, x, H, W, r);
+    double g[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = win(s_rows + (size_t)k * LW, x, x0, r, W) / base;
+    const double m0 = g[0], m1 = g[1], m2 = g[2];
+    const double s00 = g[3] - m0 * m0 + eps, s01 = g[4] - m0 * m1, s02 = g[5] - m0 * m2;
+    const double s11 = g[6] - m1 * m1 + eps, s12 = g[7] - m1 * m2, s22 = g[8] - m2 * m2 + eps;
+    // symmetric 3x3 inverse by cofactors
+    const double k00 = s11 * s22 - s12 * s12, k01 = s02 * s12 - s01 * s22, k02 = s01 * s12 - s02 * s11;
+    const double k11 = s00 * s22 - s02 * s02, k12 = s01 * s02 - s00 * s12, k22 = s00 * s11 - s01 * s01;
+    const double det = s00 * k00 + s01 * k01 + s02 * k02;
+    const size_t i = (size_t)y * W + x;
+#pragma unroll
+    for (int ip = 0; ip < NP; ++ip) {
+        const double *pr = s_rows + (size_t)(9 + 4 * ip) * LW;
+        const double mp = win(pr, x, x0, r, W) / base;
+        const double c0 = win(pr + LW, x, x0, r, W) / base - m0 * mp;
+        const double c1 = win(pr + 2 * (size_t)LW, x, x0, r, W) / base - m1 * mp;
+        const double c2 = win(pr + 3 * (size_t)LW, x, x0, r, W) / base - m2 * mp;
         const double a0 = (c0 * k00 + c1 * k01 + c2 * k02) / det;
         const double a1 = (c0 * k01 + c1 * k11 + c2 * k12) / det;
         const double a2 = (c0 * k02 + c1 * k12 + c2 * k22) / det;
+        double *o = AB + ((size_t)f * NP + ip) * 4 * n;
         o[i] = a0; o[n + i] = a1; o[2 * n + i] = a2;
         o[3 * n + i] = mp - a0 * m0 - a1 * m1 - a2 * m2;
     }
 }
 
-// ---- guided filter eq.16: q = (box(a).I + box(b)) / base ---------------------------------
-__global__ __launch_bounds__(256) void k_gf_final(const double *__restrict__ SAB /*[F*np][4]*/,
-                                                  const uint8_t *__restrict__ guide, size_t step, size_t fs,
-                                                  const int *__restrict__ gnorm, int gnorm_stride,
-                                                  double *__restrict__ Q /*[F*np]*/, int H, int W, int r, int np)
+// ---- guided filter eq.16 with the horizontal sums fused: q = (box(a).I + box(b)) / base ----
+template <int NP>
+__global__ __launch_bounds__(256) void k_gf_final_h(const double *__restrict__ VAB /*[F*NP][4] vertical sums of a,b*/,
+                                                    const uint8_t *__restrict__ guide, size_t step, size_t fs,
+                                                    const int *__restrict__ gnorm, int gnorm_stride,
+                                                    double *__restrict__ Q /*[F*NP]*/, int H, int W, int r)
 {
-    const int z = blockIdx.y, f = z / np;
+    extern __shared__ __attribute__((aligned(16))) double s_rows[];
+    constexpr int NPL = 4 * NP;
+    const int LW = HSEG + 2 * r + 1;
+    const int x0 = blockIdx.x * HSEG, y = blockIdx.y, f = blockIdx.z;
     const size_t n = (size_t)H * W;
+    const double *planes[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) planes[k] = VAB + ((size_t)f * NPL + k) * n;
+    __shared__ double s_tot[NPL * 64];
+    load_scan<NPL>(s_rows, s_tot, LW, planes, (size_t)y * W, x0, r, W);
+    const int x = x0 + threadIdx.x;
+    if (x >= W) return;
     const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
-    const double *s = SAB + (size_t)z * 4 * n;
-    const uint8_t *gb = guide + (size_t)f * fs;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
-        const uint8_t *p = gb + (size_t)y * step + (size_t)x * 3;
-        const double I0 = normv(p[0], mn, mx), I1 = normv(p[1], mn, mx), I2 = normv(p[2], mn, mx);
-        Q[(size_t)z * n + i] = (s[i] * I0 + s[n + i] * I1 + s[2 * n + i] * I2 + s[3 * n + i]) / box_base(y, x, H, W, r);
+    const uint8_t *p = guide + (size_t)f * fs + (size_t)y * step + (size_t)x * 3;
+    const double I0 = normv(p[0], mn, mx), I1 = normv(p[1], mn, mx), I2 = normv(p[2], mn, mx);
+    const double base = box_base(y, x, H, W, r);
+#pragma unroll
+    for (int ip = 0; ip < NP; ++ip) {
+        const double *sr = s_rows + (size_t)(4 * ip) * LW;
+        const double a0 = win(sr, x, x0, r, W), a1 = win(sr + LW, x, x0, r, W);
+        const double a2 = win(sr + 2 * (size_t)LW, x, x0, r, W), bb = win(sr + 3 * (size_t)LW, x, x0, r, W);
+        Q[((size_t)f * NP + ip) * n + (size_t)y * W + x] = (a0 * I0 + a1 * I1 + a2 * I2 + bb) / base;
     }
 }
 
@@ -668,40 +727,34 @@ int guided_filter_u8(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs
     UWIP_REQUIRE(ctx, H >= 2 * r + 1 && W >= 2 * r + 1, "guided filter needs rows, cols >= 2r+1 (guidedfilter.py:39-41)");
     const int rpc = std::max(64, (H + 3) / 4);
     const unsigned chunks = uwip_cdiv(H, rpc), xb = uwip_cdiv(W, 256);
-    const size_t lds = (size_t)W * sizeof(double);
-    UWIP_REQUIRE(ctx, lds <= 64 * 1024 - 64, "row too wide for the LDS prefix scan");
-    const unsigned eb = 512;   // blocks per plane-set for elementwise kernels
+    UWIP_REQUIRE(ctx, np == 1 || np == 2, "np must be 1 or 2");
+    const int LW = HSEG + 2 * r + 1;
+    const size_t lds_solve = (size_t)(9 + 4 * np) * LW * sizeof(double), lds_final = (size_t)(4 * np) * LW * sizeof(double);
+    UWIP_REQUIRE(ctx, lds_solve <= 64 * 1024 - 256 && LW <= 512 && LW <= RUNMAX * (256 / (9 + 4 * np)),
+                 "radius too large for the fused horizontal pass");
+    const dim3 gh(uwip_cdiv(W, HSEG), (unsigned)H, (unsigned)F);
+    UWIP_REQUIRE(ctx, H <= 65535 && F <= 65535, "too many rows/frames for one launch");
     {
         uwip_kscope ks(ctx, "k_vsum<guide>");
         k_vsum<0><<<dim3(xb, chunks, F), 256, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, nullptr, VG, H, W, r, rpc, np);
-    }
-    {
-        uwip_kscope ks(ctx, "k_hsum");
-        k_hsum<<<dim3(H, F * 9), 256, lds, ctx->stream>>>(VG, H, W, r);
     }
     {
         uwip_kscope ks(ctx, "k_vsum<p>");
         k_vsum<1><<<dim3(xb, chunks, F * np), 256, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, VP, H, W, r, rpc, np);
     }
     {
-        uwip_kscope ks(ctx, "k_hsum");
-        k_hsum<<<dim3(H, F * np * 4), 256, lds, ctx->stream>>>(VP, H, W, r);
-    }
-    {
-        uwip_kscope ks(ctx, "k_gf_solve");
-        k_gf_solve<<<dim3(eb, F * np), 256, 0, ctx->stream>>>(VG, VP, AB, H, W, r, eps, np);
+        uwip_kscope ks(ctx, "k_gf_solve_h");
+        if (np == 2) k_gf_solve_h<2><<<gh, 256, lds_solve, ctx->stream>>>(VG, VP, AB, H, W, r, eps);
+        else k_gf_solve_h<1><<<gh, 256, lds_solve, ctx->stream>>>(VG, VP, AB, H, W, r, eps);
     }
     {
         uwip_kscope ks(ctx, "k_vsum<plane>");
         k_vsum<2><<<dim3(xb, chunks, F * np * 4), 256, 0, ctx->stream>>>(nullptr, 0, 0, nullptr, 0, AB, VP, H, W, r, rpc, np);
     }
     {
-        uwip_kscope ks(ctx, "k_hsum");
-        k_hsum<<<dim3(H, F * np * 4), 256, lds, ctx->stream>>>(VP, H, W, r);
-    }
-    {
-        uwip_kscope ks(ctx, "k_gf_final");
-        k_gf_final<<<dim3(eb, F * np), 256, 0, ctx->stream>>>(VP, guide, step, fs, gnorm, gstride, Q, H, W, r, np);
+        uwip_kscope ks(ctx, "k_gf_final_h");
+        if (np == 2) k_gf_final_h<2><<<gh, 256, lds_final, ctx->stream>>>(VP, guide, step, fs, gnorm, gstride, Q, H, W, r);
+        else k_gf_final_h<1><<<gh, 256, lds_final, ctx->stream>>>(VP, guide, step, fs, gnorm, gstride, Q, H, W, r);
     }
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;

@@ -155,7 +155,14 @@ __global__ __launch_bounds__(256) void k_ov_kc(const float *__restrict__ Lsm, in
         uint32_t b = __float_as_uint(m);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
-        if ((threadIdx.x & 63) == 0 && b) atomicMax(&hmax_bits[f], b);
+        // one atomic per block, and only when it can raise the running maximum (max is exact: order-free)
+        __shared__ uint32_t s_mx[4];
+        if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = b;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t m4 = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
+            if (m4 > __hip_atomic_load(&hmax_bits[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&hmax_bits[f], m4);
+        }
     } else {
         const float hmax = __uint_as_float(hmax_bits[f]);
         if (in && m != 0.0f && hmax != 0.0f) {
