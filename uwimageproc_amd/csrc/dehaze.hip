@@ -287,6 +287,38 @@ __global__ __launch_bounds__(256) void k_vsum(const uint8_t *__restrict__ guide,
     }
 }
 
+// Guide statistics as exact integers: with u = v - min (0..255), sums of u_i and u_i*u_j over an 81-row window
+// fit 32 bits (81 * 255^2 = 5.3e6) and stay exact, so the nine guide planes are uint32 instead of float64.
+__global__ __launch_bounds__(256) void k_vsum_guide_u32(const uint8_t *__restrict__ guide, size_t step, size_t fs,
+                                                        const int *__restrict__ gnorm, int gnorm_stride,
+                                                        uint32_t *__restrict__ out /*[F][9][H][W]*/, int H, int W, int r,
+                                                        int rows_per_chunk)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.z;
+    if (x >= W) return;
+    const size_t n = (size_t)H * W;
+    const int mn = gnorm[(size_t)f * gnorm_stride];
+    const uint8_t *g = guide + (size_t)f * fs + (size_t)x * 3;
+    uint32_t *po = out + (size_t)f * 9 * n + x;
+    const int y0 = blockIdx.y * rows_per_chunk, y1 = min(H, y0 + rows_per_chunk);
+    uint32_t s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto accum = [&](int yy, bool add) {
+        const uint8_t *p = g + (size_t)yy * step;
+        const uint32_t a = (uint32_t)max((int)p[0] - mn, 0), b = (uint32_t)max((int)p[1] - mn, 0), c = (uint32_t)max((int)p[2] - mn, 0);
+        const uint32_t v[9] = {a, b, c, a * a, a * b, a * c, b * b, b * c, c * c};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s[k] = add ? s[k] + v[k] : s[k] - v[k];
+    };
+    for (int yy = max(0, y0 - r); yy <= min(H - 1, y0 + r); ++yy) accum(yy, true);
+    for (int y = y0; y < y1; ++y) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) po[(size_t)k * n + (size_t)y * W] = s[k];
+        if (y + r + 1 < H) accum(y + r + 1, true);
+        if (y - r >= 0) accum(y - r, false);
+    }
+}
+
 __device__ __forceinline__ double box_base(int y, int x, int H, int W, int r)
 {
     const int cy = min(y + r, H - 1) - max(y - r, 0) + 1;
@@ -308,48 +340,74 @@ constexpr int HSEG = 256;
 //  2. TPP = 256 / NPL threads own one plane each: a thread reads its contiguous run into registers,
 //     scans it there, publishes the run total, and after one barrier writes run + offset back.
 constexpr int RUNMAX = 24;
-template <int NPL>
-__device__ __forceinline__ void load_scan(double *s, double *s_tot /*[NPL][64]*/, int LW, const double *const (&planes)[NPL],
+template <int NI, int NF>
+__device__ __forceinline__ void load_scan(uint32_t *si /*[NI][LW]*/, double *sf /*[NF][LW]*/, double *s_tot /*[(NI+NF)][64]*/,
+                                          int LW, const uint32_t *const *iplanes, const double *const (&fplanes)[NF],
                                           size_t row_off, int x0, int r, int W)
 {
+    constexpr int NPL = NI + NF;
     constexpr int TPP = 256 / NPL;
     {
-        double v[NPL][2];
+        uint32_t vi[NI > 0 ? NI : 1][2];
+        double vf[NF][2];
         const int j0 = threadIdx.x, j1 = threadIdx.x + 256;
         const int xa = x0 - r - 1 + j0, xb = x0 - r - 1 + j1;
         const bool oka = xa >= 0 && xa < W, okb = j1 < LW && xb >= 0 && xb < W;
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            v[k][0] = oka ? planes[k][row_off + xa] : 0.0;
-            v[k][1] = okb ? planes[k][row_off + xb] : 0.0;
+        for (int k = 0; k < NI; ++k) {
+            vi[k][0] = oka ? iplanes[k][row_off + xa] : 0u;
+            vi[k][1] = okb ? iplanes[k][row_off + xb] : 0u;
         }
 #pragma unroll
-        for (int k = 0; k < NPL; ++k) {
-            s[(size_t)k * LW + j0] = v[k][0];
-            if (j1 < LW) s[(size_t)k * LW + j1] = v[k][1];
+        for (int k = 0; k < NF; ++k) {
+            vf[k][0] = oka ? fplanes[k][row_off + xa] : 0.0;
+            vf[k][1] = okb ? fplanes[k][row_off + xb] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            si[(size_t)k * LW + j0] = vi[k][0];
+            if (j1 < LW) si[(size_t)k * LW + j1] = vi[k][1];
+        }
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            sf[(size_t)k * LW + j0] = vf[k][0];
+            if (j1 < LW) sf[(size_t)k * LW + j1] = vf[k][1];
         }
     }
     __syncthreads();
     const int k = threadIdx.x / TPP, t = threadIdx.x - k * TPP;
     const int run = (LW + TPP - 1) / TPP;
-    const bool active = k < NPL;
-    double *row = s + (size_t)(active ? k : 0) * LW;
     const int a = t * run, e = min(a + run, LW);
-    double v[RUNMAX];
-    double acc = 0.0;
-    if (active) {
+    uint32_t *s_toti = reinterpret_cast<uint32_t *>(s_tot);
+    const bool is_i = k < NI, is_f = !is_i && k < NPL;
+    uint32_t *irow = si + (size_t)(is_i ? k : 0) * LW;
+    double *frow = sf + (size_t)(is_f ? k - NI : 0) * LW;
+    uint32_t vi[RUNMAX], acci = 0;
+    double vf[RUNMAX], accf = 0.0;
+    if (is_i) {
 #pragma unroll
-        for (int i = 0; i < RUNMAX; ++i) v[i] = (a + i < e) ? row[a + i] : 0.0;
+        for (int i = 0; i < RUNMAX; ++i) vi[i] = (a + i < e) ? irow[a + i] : 0u;
 #pragma unroll
-        for (int i = 0; i < RUNMAX; ++i) { acc += v[i]; v[i] = acc; }
-        s_tot[k * 64 + t] = acc;
+        for (int i = 0; i < RUNMAX; ++i) { acci += vi[i]; vi[i] = acci; }
+        s_toti[(k * 64 + t) * 2] = acci;
+    } else if (is_f) {
+#pragma unroll
+        for (int i = 0; i < RUNMAX; ++i) vf[i] = (a + i < e) ? frow[a + i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < RUNMAX; ++i) { accf += vf[i]; vf[i] = accf; }
+        s_tot[k * 64 + t] = accf;
     }
-    __syncthreads();
-    if (active) {
+    __syncthreads();               // one barrier for every lane, whatever its plane type
+    if (is_i) {
+        uint32_t off = 0;
+        for (int i = 0; i < t; ++i) off += s_toti[(k * 64 + i) * 2];
+#pragma unroll
+        for (int i = 0; i < RUNMAX; ++i) if (a + i < e) irow[a + i] = vi[i] + off;
+    } else if (is_f) {
         double off = 0.0;
         for (int i = 0; i < t; ++i) off += s_tot[k * 64 + i];
 #pragma unroll
-        for (int i = 0; i < RUNMAX; ++i) if (a + i < e) row[a + i] = v[i] + off;
+        for (int i = 0; i < RUNMAX; ++i) if (a + i < e) frow[a + i] = vf[i] + off;
     }
     __syncthreads();
 }
@@ -361,48 +419,63 @@ __device__ __forceinline__ double win(const double *row, int x, int x0, int r, i
     return row[min(x + r, W - 1) - o] - row[max(x - r, 0) - 1 - o];
 }
 
+__device__ __forceinline__ uint32_t win_u32(const uint32_t *row, int x, int x0, int r, int W)
+{
+    const int o = x0 - r - 1;
+    return row[min(x + r, W - 1) - o] - row[max(x - r, 0) - 1 - o];       // exact (mod 2^32, true value < 2^32)
+}
+
 // ---- guided filter eq.14-15 with the horizontal sums fused: a = cov inv(Sigma + eps I), b = mean_p - a.mean
 template <int NP>
-__global__ __launch_bounds__(256) void k_gf_solve_h(const double *__restrict__ VG /*[F][9] vertical sums*/,
+__global__ __launch_bounds__(256) void k_gf_solve_h(const uint32_t *__restrict__ VG /*[F][9] vertical integer sums*/,
                                                     const double *__restrict__ VP /*[F*NP][4] vertical sums*/,
-                                                    double *__restrict__ AB /*[F*NP][4]*/, int H, int W, int r, double eps)
+                                                    double *__restrict__ AB /*[F*NP][4]*/, int H, int W, int r, double eps,
+                                                    const int *__restrict__ gnorm, int gnorm_stride)
 {
     extern __shared__ __attribute__((aligned(16))) double s_rows[];
-    constexpr int NPL = 9 + 4 * NP;
+    constexpr int NF = 4 * NP;
     const int LW = HSEG + 2 * r + 1;
+    double *sf = s_rows;                                                   // [NF][LW] float64
+    uint32_t *si = reinterpret_cast<uint32_t *>(s_rows + (size_t)NF * LW); // [9][LW] uint32
+    __shared__ double s_tot[(9 + NF) * 64];
     const int x0 = blockIdx.x * HSEG, y = blockIdx.y, f = blockIdx.z;
     const size_t n = (size_t)H * W;
-    const double *planes[NPL];
+    const uint32_t *iplanes[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) planes[k] = VG + ((size_t)f * 9 + k) * n;
+    for (int k = 0; k < 9; ++k) iplanes[k] = VG + ((size_t)f * 9 + k) * n;
+    const double *fplanes[NF];
 #pragma unroll
-    for (int k = 0; k < 4 * NP; ++k) planes[9 + k] = VP + ((size_t)f * NP * 4 + k) * n;
-    __shared__ double s_tot[NPL * 64];
-    load_scan<NPL>(s_rows, s_tot, LW, planes, (size_t)y * W, x0, r, W);
+    for (int k = 0; k < NF; ++k) fplanes[k] = VP + ((size_t)f * NF + k) * n;
+    load_scan<9, NF>(si, sf, s_tot, LW, iplanes, fplanes, (size_t)y * W, x0, r, W);
     const int x = x0 + threadIdx.x;
     if (x >= W) return;
-    const double base = box_base(y, x, H, W, r);
+    // reciprocals instead of ~30 float64 divisions per pixel (differs from true division by <= 1 ulp)
+    const double rbase = 1.0 / box_base(y, x, H, W, r);
+    const double rdd = 1.0 / (double)(gnorm[(size_t)f * gnorm_stride + 1] - gnorm[(size_t)f * gnorm_stride]);
+    const double r1 = rdd * rbase, r2 = (rdd * rdd) * rbase;
     double g[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) g[k] = win(s_rows + (size_t)k * LW, x, x0, r, W) / base;
+    for (int k = 0; k < 3; ++k) g[k] = (double)win_u32(si + (size_t)k * LW, x, x0, r, W) * r1;
+#pragma unroll
+    for (int k = 3; k < 9; ++k) g[k] = (double)win_u32(si + (size_t)k * LW, x, x0, r, W) * r2;
     const double m0 = g[0], m1 = g[1], m2 = g[2];
     const double s00 = g[3] - m0 * m0 + eps, s01 = g[4] - m0 * m1, s02 = g[5] - m0 * m2;
     const double s11 = g[6] - m1 * m1 + eps, s12 = g[7] - m1 * m2, s22 = g[8] - m2 * m2 + eps;
     // symmetric 3x3 inverse by cofactors
     const double k00 = s11 * s22 - s12 * s12, k01 = s02 * s12 - s01 * s22, k02 = s01 * s12 - s02 * s11;
     const double k11 = s00 * s22 - s02 * s02, k12 = s01 * s02 - s00 * s12, k22 = s00 * s11 - s01 * s01;
-    const double det = s00 * k00 + s01 * k01 + s02 * k02;
+    const double rdet = 1.0 / (s00 * k00 + s01 * k01 + s02 * k02);
     const size_t i = (size_t)y * W + x;
 #pragma unroll
     for (int ip = 0; ip < NP; ++ip) {
-        const double *pr = s_rows + (size_t)(9 + 4 * ip) * LW;
-        const double mp = win(pr, x, x0, r, W) / base;
-        const double c0 = win(pr + LW, x, x0, r, W) / base - m0 * mp;
-        const double c1 = win(pr + 2 * (size_t)LW, x, x0, r, W) / base - m1 * mp;
-        const double c2 = win(pr + 3 * (size_t)LW, x, x0, r, W) / base - m2 * mp;
-        const double a0 = (c0 * k00 + c1 * k01 + c2 * k02) / det;
-        const double a1 = (c0 * k01 + c1 * k11 + c2 * k12) / det;
-        const double a2 = (c0 * k02 + c1 * k12 + c2 * k22) / det;
+        const double *pr = sf + (size_t)(4 * ip) * LW;
+        const double mp = win(pr, x, x0, r, W) * rbase;
+        const double c0 = win(pr + LW, x, x0, r, W) * rbase - m0 * mp;
+        const double c1 = win(pr + 2 * (size_t)LW, x, x0, r, W) * rbase - m1 * mp;
+        const double c2 = win(pr + 3 * (size_t)LW, x, x0, r, W) * rbase - m2 * mp;
+        const double a0 = (c0 * k00 + c1 * k01 + c2 * k02) * rdet;
+        const double a1 = (c0 * k01 + c1 * k11 + c2 * k12) * rdet;
+        const double a2 = (c0 * k02 + c1 * k12 + c2 * k22) * rdet;
         double *o = AB + ((size_t)f * NP + ip) * 4 * n;
         o[i] = a0; o[n + i] = a1; o[2 * n + i] = a2;
         o[3 * n + i] = mp - a0 * m0 - a1 * m1 - a2 * m2;
@@ -425,19 +498,19 @@ __global__ __launch_bounds__(256) void k_gf_final_h(const double *__restrict__ V
 #pragma unroll
     for (int k = 0; k < NPL; ++k) planes[k] = VAB + ((size_t)f * NPL + k) * n;
     __shared__ double s_tot[NPL * 64];
-    load_scan<NPL>(s_rows, s_tot, LW, planes, (size_t)y * W, x0, r, W);
+    load_scan<0, NPL>(nullptr, s_rows, s_tot, LW, nullptr, planes, (size_t)y * W, x0, r, W);
     const int x = x0 + threadIdx.x;
     if (x >= W) return;
     const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
     const uint8_t *p = guide + (size_t)f * fs + (size_t)y * step + (size_t)x * 3;
     const double I0 = normv(p[0], mn, mx), I1 = normv(p[1], mn, mx), I2 = normv(p[2], mn, mx);
-    const double base = box_base(y, x, H, W, r);
+    const double rbase = 1.0 / box_base(y, x, H, W, r);
 #pragma unroll
     for (int ip = 0; ip < NP; ++ip) {
         const double *sr = s_rows + (size_t)(4 * ip) * LW;
         const double a0 = win(sr, x, x0, r, W), a1 = win(sr + LW, x, x0, r, W);
         const double a2 = win(sr + 2 * (size_t)LW, x, x0, r, W), bb = win(sr + 3 * (size_t)LW, x, x0, r, W);
-        Q[((size_t)f * NP + ip) * n + (size_t)y * W + x] = (a0 * I0 + a1 * I1 + a2 * I2 + bb) / base;
+        Q[((size_t)f * NP + ip) * n + (size_t)y * W + x] = (a0 * I0 + a1 * I1 + a2 * I2 + bb) * rbase;
     }
 }
 
@@ -729,14 +802,16 @@ int guided_filter_u8(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs
     const unsigned chunks = uwip_cdiv(H, rpc), xb = uwip_cdiv(W, 256);
     UWIP_REQUIRE(ctx, np == 1 || np == 2, "np must be 1 or 2");
     const int LW = HSEG + 2 * r + 1;
-    const size_t lds_solve = (size_t)(9 + 4 * np) * LW * sizeof(double), lds_final = (size_t)(4 * np) * LW * sizeof(double);
+    const size_t lds_solve = (size_t)(4 * np) * LW * sizeof(double) + (size_t)9 * LW * sizeof(uint32_t);
+    const size_t lds_final = (size_t)(4 * np) * LW * sizeof(double);
+    UWIP_REQUIRE(ctx, (uint64_t)LW * (2 * r + 1) * 65025ull < (1ull << 32), "window too large for the exact integer guide sums");
     UWIP_REQUIRE(ctx, lds_solve <= 64 * 1024 - 256 && LW <= 512 && LW <= RUNMAX * (256 / (9 + 4 * np)),
                  "radius too large for the fused horizontal pass");
     const dim3 gh(uwip_cdiv(W, HSEG), (unsigned)H, (unsigned)F);
     UWIP_REQUIRE(ctx, H <= 65535 && F <= 65535, "too many rows/frames for one launch");
     {
         uwip_kscope ks(ctx, "k_vsum<guide>");
-        k_vsum<0><<<dim3(xb, chunks, F), 256, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, nullptr, VG, H, W, r, rpc, np);
+        k_vsum_guide_u32<<<dim3(xb, chunks, F), 256, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, (uint32_t *)VG, H, W, r, rpc);
     }
     {
         uwip_kscope ks(ctx, "k_vsum<p>");
@@ -744,8 +819,8 @@ int guided_filter_u8(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs
     }
     {
         uwip_kscope ks(ctx, "k_gf_solve_h");
-        if (np == 2) k_gf_solve_h<2><<<gh, 256, lds_solve, ctx->stream>>>(VG, VP, AB, H, W, r, eps);
-        else k_gf_solve_h<1><<<gh, 256, lds_solve, ctx->stream>>>(VG, VP, AB, H, W, r, eps);
+        if (np == 2) k_gf_solve_h<2><<<gh, 256, lds_solve, ctx->stream>>>((const uint32_t *)VG, VP, AB, H, W, r, eps, gnorm, gstride);
+        else k_gf_solve_h<1><<<gh, 256, lds_solve, ctx->stream>>>((const uint32_t *)VG, VP, AB, H, W, r, eps, gnorm, gstride);
     }
     {
         uwip_kscope ks(ctx, "k_vsum<plane>");
