@@ -798,8 +798,15 @@ int guided_filter_u8(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs
                      int r, double eps)
 {
     UWIP_REQUIRE(ctx, H >= 2 * r + 1 && W >= 2 * r + 1, "guided filter needs rows, cols >= 2r+1 (guidedfilter.py:39-41)");
-    const int rpc = std::max(64, (H + 3) / 4);
-    const unsigned chunks = uwip_cdiv(H, rpc), xb = uwip_cdiv(W, 256);
+    // row chunks per column: every chunk re-reads a 2r+1 row window and adds one more lag window to the cache
+    // footprint, so use one chunk whenever the batch alone yields >= ~2048 blocks
+    auto chunks_for = [&](int zcount) {
+        const size_t blocks1 = (size_t)uwip_cdiv(W, 256) * zcount;
+        const int want = (int)((2048 + blocks1 - 1) / blocks1);
+        return std::max(1, std::min(std::min(want, 8), std::max(1, H / 64)));
+    };
+    auto rpc_for = [&](int zcount) { const int c = chunks_for(zcount); return (H + c - 1) / c; };
+    const unsigned xb = uwip_cdiv(W, 256);
     UWIP_REQUIRE(ctx, np == 1 || np == 2, "np must be 1 or 2");
     const int LW = HSEG + 2 * r + 1;
     const size_t lds_solve = (size_t)(4 * np) * LW * sizeof(double) + (size_t)9 * LW * sizeof(uint32_t);
@@ -811,11 +818,11 @@ int guided_filter_u8(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs
     UWIP_REQUIRE(ctx, H <= 65535 && F <= 65535, "too many rows/frames for one launch");
     {
         uwip_kscope ks(ctx, "k_vsum<guide>");
-        k_vsum_guide_u32<<<dim3(xb, chunks, F), 256, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, (uint32_t *)VG, H, W, r, rpc);
+        k_vsum_guide_u32<<<dim3(xb, uwip_cdiv(H, rpc_for(F)), F), 256, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, (uint32_t *)VG, H, W, r, rpc_for(F));
     }
     {
         uwip_kscope ks(ctx, "k_vsum<p>");
-        k_vsum<1><<<dim3(xb, chunks, F * np), 256, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, VP, H, W, r, rpc, np);
+        k_vsum<1><<<dim3(xb, uwip_cdiv(H, rpc_for(F * np)), F * np), 256, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, VP, H, W, r, rpc_for(F * np), np);
     }
     {
         uwip_kscope ks(ctx, "k_gf_solve_h");
@@ -824,7 +831,7 @@ int guided_filter_u8(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs
     }
     {
         uwip_kscope ks(ctx, "k_vsum<plane>");
-        k_vsum<2><<<dim3(xb, chunks, F * np * 4), 256, 0, ctx->stream>>>(nullptr, 0, 0, nullptr, 0, AB, VP, H, W, r, rpc, np);
+        k_vsum<2><<<dim3(xb, uwip_cdiv(H, rpc_for(F * np * 4)), F * np * 4), 256, 0, ctx->stream>>>(nullptr, 0, 0, nullptr, 0, AB, VP, H, W, r, rpc_for(F * np * 4), np);
     }
     {
         uwip_kscope ks(ctx, "k_gf_final_h");
