@@ -299,8 +299,8 @@ struct CellItem {
 // Same-bin LDS atomics from one wave serialise, and neighbouring pixels of a smooth underwater frame land in
 // few bins: the output histograms are therefore replicated SWEEP_REP times, keyed by the low lane bits, and
 // a block is 1024 threads (16 waves share one set of packed LUTs + replicas: 85 KB of LDS, one block per CU).
-constexpr int SWEEP_THREADS = 1024;
-constexpr int SWEEP_REP = 4;
+constexpr int SWEEP_THREADS = 512;
+constexpr int SWEEP_REP = 2;
 constexpr int SWEEP_RSTRIDE = SWEEP_GROUP * 256 + 8;   // +8 words: equal bins of different replicas fall in different LDS banks
 __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__restrict__ src, size_t step,
                                                      size_t fstride, int gx, int gy, float inv_tw,
@@ -314,6 +314,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
     extern __shared__ __attribute__((aligned(16))) uint32_t s_sweep[];
     uint32_t *s_pack = s_sweep;                                   // [SWEEP_GROUP][256]
     uint32_t *s_hist = s_sweep + SWEEP_GROUP * 256;               // [SWEEP_REP][SWEEP_GROUP][256]
+    __shared__ uint32_t s_diff[SWEEP_GROUP];
     const int tid = threadIdx.x;
     const int cg = blockIdx.y, f = blockIdx.z;
     const int tiles = gx * gy;
@@ -322,6 +323,8 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
     const uint8_t *fb = src + (size_t)f * fstride;
     const uint8_t *L = luts + ((size_t)f * SWEEP_NCL + (size_t)cg * SWEEP_GROUP) * tiles * 256;
     const int i0 = blockIdx.x * items_per_block, i1 = min(nitems, i0 + items_per_block);
+    const bool single = (i1 - i0) == 1;
+    uint32_t last_mask = 0xffffffffu;
     for (int it = i0; it < i1; ++it) {
         const CellItem ci = items[it];
         const int tx1 = max(ci.cx - 1, 0), tx2 = min(ci.cx, gx - 1);
@@ -336,30 +339,55 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
             const uint32_t d = Lc[((size_t)ty2 * gx + tx2) * 256 + v];
             s_pack[idx] = a | (b << 8) | (cc << 16) | (d << 24);
         }
+        if (tid < SWEEP_GROUP) s_diff[tid] = tid == 0 ? 1u : 0u;
         __syncthreads();
+        // a clip limit above the tallest bin of all four tiles leaves their LUTs unchanged: when clip limit c has
+        // byte-identical packed LUTs to c-1 in this cell, every pixel's output repeats and need not be recomputed
+        for (int idx = tid + 256; idx < SWEEP_GROUP * 256; idx += SWEEP_THREADS)
+            if (s_pack[idx] != s_pack[idx - 256]) s_diff[idx >> 8] = 1u;
+        __syncthreads();
+        uint32_t diffmask = 0;
+#pragma unroll
+        for (int c = 0; c < SWEEP_GROUP; ++c) diffmask |= (s_diff[c] ? 1u : 0u) << c;
+        diffmask = __builtin_amdgcn_readfirstlane(diffmask);
+        last_mask = diffmask;
         const int w = ci.x1 - ci.x0;
         const int npix = w * (ci.r1 - ci.r0);
         const float inv_w = 1.0f / (float)w;
-        for (int p = tid; p < npix; p += SWEEP_THREADS) {
+        // pixel p of the cell -> (x, y); the byte for the NEXT iteration is requested before this one's 17
+        // evaluations so its latency hides behind them
+        auto locate = [&](int p, int &x, int &y) {
             int q = (int)(((float)p + 0.5f) * inv_w);
             int r = p - q * w;
             if (r < 0) { q--; r += w; }
             if (r >= w) { q++; r -= w; }
-            const int x = ci.x0 + r, y = ci.r0 + q;
+            x = ci.x0 + r; y = ci.r0 + q;
+        };
+        int xn = 0, yn = 0;
+        uint32_t vnext = 0;
+        if (tid < npix) { locate(tid, xn, yn); vnext = fb[(size_t)yn * step + xn]; }
+        for (int p = tid; p < npix; p += SWEEP_THREADS) {
+            const int x = xn, y = yn;
+            const uint32_t v = vnext;
+            if (p + SWEEP_THREADS < npix) { locate(p + SWEEP_THREADS, xn, yn); vnext = fb[(size_t)yn * step + xn]; }
             const float txf = (float)x * inv_tw - 0.5f;
             const float xa = txf - floorf(txf), xa1 = 1.0f - xa;
             const float tyf = (float)y * inv_th - 0.5f;
             const float ya = tyf - floorf(tyf), ya1 = 1.0f - ya;
             const f32x2 xa1v = {xa1, xa1}, xav = {xa, xa}, yv = {ya1, ya};
-            const uint32_t v = fb[(size_t)y * step + x];
+            uint32_t o = 0;
 #pragma unroll
             for (int c = 0; c < SWEEP_GROUP; ++c) {
-                const uint32_t pk = s_pack[c * 256 + v];
-                // (TL*xa1 + TR*xa)*ya1 + (BL*xa1 + BR*xa)*ya, two rows per packed-f32 pair (same op order, no FMA)
-                const f32x2 ac = {(float)(pk & 255u), (float)((pk >> 16) & 255u)};
-                const f32x2 bd = {(float)((pk >> 8) & 255u), (float)(pk >> 24)};
-                const f32x2 t = (ac * xa1v + bd * xav) * yv;
-                const uint32_t o = __builtin_amdgcn_cvt_pk_u8_f32(t.x + t.y, 0, 0u);     // RNE + clamp
+                if (diffmask & (1u << c)) {          // wave-uniform
+                    const uint32_t pk = s_pack[c * 256 + v];
+                    // (TL*xa1 + TR*xa)*ya1 + (BL*xa1 + BR*xa)*ya, two rows per packed-f32 pair (same op order, no FMA)
+                    const f32x2 ac = {(float)(pk & 255u), (float)((pk >> 16) & 255u)};
+                    const f32x2 bd = {(float)((pk >> 8) & 255u), (float)(pk >> 24)};
+                    const f32x2 t = (ac * xa1v + bd * xav) * yv;
+                    o = __builtin_amdgcn_cvt_pk_u8_f32(t.x + t.y, 0, 0u);     // RNE + clamp
+                } else if (single) {
+                    continue;                        // one cell per block: the repeated histogram is copied at flush time
+                }
                 atomicAdd(&my_hist[c * 256 + o], 1u);
             }
         }
@@ -367,9 +395,16 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
     __syncthreads();
     uint32_t *out = out_hist + (size_t)f * out_fs + (size_t)cg * SWEEP_GROUP * 256;
     for (int i = tid; i < SWEEP_GROUP * 256; i += SWEEP_THREADS) {
+        int src = i;
+        if (single) {
+            // clip limit c repeated the outputs of the nearest lower clip limit whose LUTs differed
+            const int c = i >> 8;
+            const uint32_t m = last_mask & ((2u << c) - 1u);
+            src = ((31 - __builtin_clz(m | 1u)) << 8) | (i & 255);
+        }
         uint32_t sum = 0;
 #pragma unroll
-        for (int r = 0; r < SWEEP_REP; ++r) sum += s_hist[r * SWEEP_RSTRIDE + i];
+        for (int r = 0; r < SWEEP_REP; ++r) sum += s_hist[r * SWEEP_RSTRIDE + src];
         if (sum) atomicAdd(&out[i], sum);
     }
 }
@@ -698,7 +733,7 @@ UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int resi
         const CellItem *d_items = (const CellItem *)d_tab;
         const int nitems = (int)(bytes / sizeof(CellItem));
         const int cell_px = std::max(1, g.tw * g.th);
-        const int ipb = std::max(1, std::min(64, 65536 / cell_px));
+        const int ipb = std::max(1, std::min(32, 32768 / cell_px));
         dim3 grid(uwip_cdiv(nitems, ipb), SWEEP_NCL / SWEEP_GROUP, (unsigned)F);
         uwip_kscope ks(ctx, "k_clahe_sweep");
         const size_t sweep_lds = sizeof(uint32_t) * ((size_t)SWEEP_GROUP * 256 + (size_t)SWEEP_REP * SWEEP_RSTRIDE);
