@@ -153,35 +153,55 @@ __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restric
 }
 
 // ---- C1b: clip, redistribute, cumulative LUT --------------------------------
-__global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ hists, int tiles,
+// One wave per (tile, frame); lane l owns bins 4l..4l+3 and the wave walks all clip limits with shuffle-only
+// reductions and scans (no barriers).  Arithmetic is cv::CLAHE's: integer clip / redistribute, then
+// lut = sat_u8(rne(float(cumsum) * lutScale)).
+__global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ hists, int tiles, int nf,
                                                    float lutScale, ClipList cl,
                                                    const int *__restrict__ frame_clip, int rule,
                                                    uint8_t *__restrict__ luts)
 {
-    __shared__ uint32_t scratch[8];
-    const int v = threadIdx.x;
-    const int t = blockIdx.x, c = blockIdx.y, f = blockIdx.z;
-    const int ncl = gridDim.y;
-    int h = (int)hists[((size_t)f * tiles + t) * 256 + v];
-    const int clip = frame_clip ? frame_clip[f] : cl.clip[c];
-    if (clip > 0) {
-        const int excess = max(h - clip, 0);
-        h = min(h, clip);
-        const int clipped = (int)block256_sum_u32((uint32_t)excess, scratch);
-        const int batch = clipped / 256;
-        int residual = clipped - batch * 256;
-        h += batch;
-        if (residual != 0) {
-            if (rule == 0) {                                   // OpenCV 3.4.x
-                const int stepr = max(256 / residual, 1);
-                if (v % stepr == 0 && v / stepr < residual) h++;
-            } else {                                           // OpenCV 3.2
-                if (v < residual) h++;
+    const int lane = threadIdx.x & 63;
+    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= (long long)tiles * nf) return;
+    const int f = (int)(wv / tiles), t = (int)(wv - (long long)f * tiles);
+    const uint4 hv = *reinterpret_cast<const uint4 *>(hists + ((size_t)f * tiles + t) * 256 + lane * 4);
+    const int h0[4] = {(int)hv.x, (int)hv.y, (int)hv.z, (int)hv.w};
+    const int ncl = cl.n;
+    for (int c = 0; c < ncl; ++c) {
+        const int clip = frame_clip ? frame_clip[f] : cl.clip[c];
+        int h[4] = {h0[0], h0[1], h0[2], h0[3]};
+        if (clip > 0) {
+            int excess = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { excess += max(h[k] - clip, 0); h[k] = min(h[k], clip); }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) excess += __shfl_xor(excess, d, 64);
+            const int batch = excess / 256;
+            const int residual = excess - batch * 256;
+            const int stepr = residual ? max(256 / residual, 1) : 1;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int v = lane * 4 + k;
+                h[k] += batch;
+                if (residual != 0) {
+                    if (rule == 0) { if (v % stepr == 0 && v / stepr < residual) h[k]++; }     // OpenCV 3.4.x
+                    else if (v < residual) h[k]++;                                             // OpenCV 3.2
+                }
             }
         }
+        const int p0 = h[0], p1 = p0 + h[1], p2 = p1 + h[2], p3 = p2 + h[3];
+        int incl = p3;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += o;
+        }
+        const int off = incl - p3;
+        const uint32_t w = sat_u8_rne((float)(off + p0) * lutScale) | (sat_u8_rne((float)(off + p1) * lutScale) << 8) |
+                           (sat_u8_rne((float)(off + p2) * lutScale) << 16) | (sat_u8_rne((float)(off + p3) * lutScale) << 24);
+        *reinterpret_cast<uint32_t *>(luts + (((size_t)f * ncl + c) * tiles + t) * 256 + lane * 4) = w;
     }
-    const uint32_t sum = block256_incl_scan_u32((uint32_t)h, scratch + 4);
-    luts[(((size_t)f * ncl + c) * tiles + t) * 256 + v] = (uint8_t)sat_u8_rne((float)(int)sum * lutScale);
 }
 
 // ---- pack the four neighbour LUTs of every interpolation cell: one uint32 per grey level --------
@@ -453,9 +473,8 @@ int launch_lut(uwip_ctx *ctx, const ClaheGeom &g, const uint32_t *d_hists, const
                const int *d_frame_clip, int nf, int rule, uint8_t *d_luts)
 {
     const int tiles = g.gx * g.gy;
-    dim3 grid((unsigned)tiles, (unsigned)cl.n, (unsigned)nf);
     uwip_kscope ks(ctx, "k_clahe_lut");
-    k_clahe_lut<<<grid, 256, 0, ctx->stream>>>(d_hists, tiles, g.lutScale, cl, d_frame_clip, rule, d_luts);
+    k_clahe_lut<<<uwip_cdiv((size_t)tiles * nf, 4), 256, 0, ctx->stream>>>(d_hists, tiles, nf, g.lutScale, cl, d_frame_clip, rule, d_luts);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
