@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=32, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step")
     ap.add_argument("--rows", type=int, default=1080)
     ap.add_argument("--cols", type=int, default=1920)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -77,6 +77,19 @@ def cpu_baseline(rows, cols, full_rows, full_cols):
     parts = {"dehaze_s": (t1 - t0) * scale, "histretch_sweep_s": (t2 - t1) * scale, "select_s": t3 - t2,
              "clahe_hsv_s": (t4 - t3) * scale, "overlap_s": overlap}
     return sum(parts.values()), parts
+
+
+def pmc_traffic(kernel, rows, cols, frames_per_launch):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
+    MI355X_MICROARCH.md prescribes; tools/prof_summary.py writes profiles/pmc_traffic.json).  The counters are
+    collected offline in their own rocprofv3 runs, so this is looked up, not measured in this process;
+    None when no matching profile is committed."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        e = d.get(f"{cols}x{rows}", {}).get(kernel)
+        return None if e is None else e["hbm_bytes_per_frame"] * frames_per_launch
+    except Exception:
+        return None
 
 
 def main():
@@ -147,7 +160,7 @@ def main():
             avg_ms = ms / cnt
             achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "k_clahe_apply", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_clahe_apply", H, W, F * nprof / cnt), "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_launch": per_launch_bytes}
 
     if rank == 0:
