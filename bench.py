@@ -97,18 +97,25 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback)"
+    # one process per GPU; UWIP_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing smoke test only)
+    backend = os.environ.get("UWIP_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from uwimageproc_amd import synth
     from uwimageproc_amd.pipeline import FramePipe
 
     F, H, W = args.frames, args.rows, args.cols
-    pipe = FramePipe(local_rank, F, H, W)
+    pipe = FramePipe(dev_index, F, H, W)
     # a few distinct synthetic frames, tiled to the batch (seed = 1234 + index)
     distinct = min(F, 8)
     base = synth.uw_stream(rank * 100, distinct, H, W)
@@ -133,11 +140,8 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from uwimageproc_amd import sharding
+    dt = sharding.max_over_ranks(dt)          # the slowest rank defines the step time
 
     # per-kernel timing pass (HIP events on the launch stream, inside libuwip)
     roof = None

@@ -157,3 +157,17 @@ def test_dehaze_1080p_properties(ctx):
     B = bg.Background_light(ctx, t, 15)
     tr = bg.transmission_map(ctx, t, B).cpu().numpy()[0]
     assert (tr[:, :7] == 1).all() and (tr[:, -7:] == 1).all() and tr.min() >= 0
+
+
+@pytest.mark.parametrize("shape", [(101, 131), (83, 257), (205, 300)])
+def test_dehaze_ragged_sizes_vs_oracle(ctx, shape):
+    """odd widths/heights: partial row segments of the fused horizontal pass, partial column blocks of the
+    vertical passes, window tiles that straddle the border"""
+    img = synth.uw_frame(700 + shape[0], *shape)
+    exp_f = dz.RC_correction(dz.normalize_input(img), 15)
+    res = bg.dehaze(ctx, _dev(img), 15, full=False, want_float=True, want_refined_t=True)
+    assert np.abs(res["float"].cpu().numpy()[0] - exp_f).max() <= TOL
+    B, _ = dz.background_light(dz.normalize_input(img), 15)
+    tb, tg = dz.refined_t(dz.normalize_input(img), B)
+    rt = res["refined_t"].cpu().numpy()[0]
+    assert np.abs(rt[0] - tb).max() <= TOL and np.abs(rt[1] - tg).max() <= TOL
