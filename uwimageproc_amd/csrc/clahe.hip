@@ -756,11 +756,8 @@ UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int resi
         dim3 grid(uwip_cdiv(nitems, ipb), SWEEP_NCL / SWEEP_GROUP, (unsigned)F);
         uwip_kscope ks(ctx, "k_clahe_sweep");
         const size_t sweep_lds = sizeof(uint32_t) * ((size_t)SWEEP_GROUP * 256 + (size_t)SWEEP_REP * SWEEP_RSTRIDE);
-        static bool sweep_attr = false;          // > 64 KiB of dynamic LDS needs an explicit opt-in
-        if (!sweep_attr) {
-            UWIP_HIP(ctx, hipFuncSetAttribute((const void *)k_clahe_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sweep_lds));
-            sweep_attr = true;
-        }
+        rc = uwip_lds_optin(ctx, "k_clahe_sweep", (const void *)k_clahe_sweep, sweep_lds);
+        if (rc) return rc;
         k_clahe_sweep<<<grid, SWEEP_THREADS, sweep_lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.gx,
                                                      g.gy, g.inv_tw, g.inv_th, d_luts, d_items, nitems, ipb,
                                                      d_out + (size_t)gi * SWEEP_NCL * 256, out_fs);

@@ -166,6 +166,14 @@ const void *uwip_table_put(uwip_ctx *ctx, const std::string &key, const void *ho
     return b.ptr;
 }
 
+int uwip_lds_optin(uwip_ctx *ctx, const char *name, const void *func, size_t bytes)
+{
+    if (ctx->lds_optin[name]) return UWIP_OK;
+    UWIP_HIP(ctx, hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    ctx->lds_optin[name] = true;
+    return UWIP_OK;
+}
+
 // ---- profiling ---------------------------------------------------------
 
 static hipEvent_t take_event(uwip_ctx *ctx)

@@ -277,16 +277,17 @@ __global__ __launch_bounds__(256) void k_transmission(const uint8_t *__restrict_
 }
 
 // ---- vertical sliding-window sums ------------------------------------------------
-// MODE 0: guide statistics from the u8 guide: 9 planes (I0 I1 I2 I00 I01 I02 I11 I12 I22)
 // MODE 1: per-p statistics: 4 planes (p, I0 p, I1 p, I2 p); blockIdx.z = f*np + ip
 // MODE 2: plain planes: blockIdx.z = plane
+// (the nine guide statistics are exact integers: k_vsum_guide_u32 below)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_vsum(const uint8_t *__restrict__ guide, size_t step, size_t fs,
                                               const int *__restrict__ gnorm /*[F][2]*/, int gnorm_stride,
                                               const double *__restrict__ in, double *__restrict__ out,
                                               int H, int W, int r, int rows_per_chunk, int np)
 {
-    constexpr int NS = MODE == 0 ? 9 : (MODE == 1 ? 4 : 1);
+    static_assert(MODE == 1 || MODE == 2, "guide statistics use k_vsum_guide_u32");
+    constexpr int NS = MODE == 1 ? 4 : 1;
     __shared__ double s_T[256];
     const int x = blockIdx.x * 256 + threadIdx.x;
     const int z = blockIdx.z;
@@ -299,20 +300,14 @@ __global__ __launch_bounds__(256) void k_vsum(const uint8_t *__restrict__ guide,
     }
     if (x >= W) return;
     const uint8_t *g = MODE != 2 ? guide + (size_t)f * fs + (size_t)x * 3 : nullptr;
-    const double *pin = MODE != 0 ? in + (size_t)z * n + x : nullptr;
+    const double *pin = in + (size_t)z * n + x;
     double *po = out + (size_t)z * NS * n + x;
     const int y0 = blockIdx.y * rows_per_chunk, y1 = min(H, y0 + rows_per_chunk);
     double s[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) s[k] = 0.0;
     auto accum = [&](int yy, double sign) {
-        if (MODE == 0) {
-            const uint8_t *p = g + (size_t)yy * step;
-            const double a = s_T[p[0]], b = s_T[p[1]], c = s_T[p[2]];
-            s[0] += sign * a; s[1] += sign * b; s[2] += sign * c;
-            s[3] += sign * (a * a); s[4] += sign * (a * b); s[5] += sign * (a * c);
-            s[6] += sign * (b * b); s[7] += sign * (b * c); s[8] += sign * (c * c);
-        } else if (MODE == 1) {
+        if (MODE == 1) {
             const uint8_t *p = g + (size_t)yy * step;
             const double a = s_T[p[0]], b = s_T[p[1]], c = s_T[p[2]];
             const double pv = pin[(size_t)yy * W];

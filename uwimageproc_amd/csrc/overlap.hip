@@ -272,14 +272,14 @@ __global__ __launch_bounds__(256) void k_ov_ldet(const float *__restrict__ Lx, c
 }
 
 // ---- extrema: candidate response map over all levels ------------------------------------------------
-// Ldet: [F][NLEV][h][w]; cand: same shape, response or 0
-__global__ __launch_bounds__(256) void k_ov_extrema(const float *__restrict__ Ldet, float *__restrict__ cand, int h, int w)
+// Ldet: [NLEV][F][h][w] (each level a dense batch); cand: [F][NLEV][h][w], response or 0
+__global__ __launch_bounds__(256) void k_ov_extrema(const float *__restrict__ Ldet, float *__restrict__ cand, int h, int w, int F)
 {
     const int f = blockIdx.z / NLEV, lv = blockIdx.z % NLEV;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const size_t n = (size_t)h * w;
-    const float *D = Ldet + ((size_t)f * NLEV + lv) * n;
+    const float *D = Ldet + ((size_t)lv * F + f) * n;
     float out = 0.0f;
     if (x >= BORDER && x < w - BORDER && y >= BORDER && y < h - BORDER) {
         const float v = D[(size_t)y * w + x];
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void k_ov_extrema(const float *__restrict__ Ld
         for (int o = -1; o <= 1 && ok; o += 2) {
             const int l2 = lv + o;
             if (l2 < 0 || l2 >= NLEV) continue;
-            const float *E = Ldet + ((size_t)f * NLEV + l2) * n;
+            const float *E = Ldet + ((size_t)l2 * F + f) * n;
             for (int dy = -1; dy <= 1; ++dy)
                 for (int dx = -1; dx <= 1; ++dx)
                     if (!(v > E[(size_t)(y + dy) * w + x + dx])) ok = false;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(256) void k_ov_scan_chunks(uint32_t *__restrict__ c
 
 __global__ __launch_bounds__(256) void k_ov_compact(const float *__restrict__ cand, const float *__restrict__ Ldet, int h, int w,
                                                    const uint32_t *__restrict__ sel, const uint32_t *__restrict__ offsets,
-                                                   int nchunks, Keypoint *__restrict__ kps)
+                                                   int nchunks, Keypoint *__restrict__ kps, int F)
 {
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t s_base;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void k_ov_compact(const float *__restrict__ ca
             const int lv = (int)(i / n);
             const size_t r = i - (size_t)lv * n;
             const int y = (int)(r / w), x = (int)(r - (size_t)y * w);
-            const float *D = Ldet + ((size_t)f * NLEV + lv) * n;
+            const float *D = Ldet + ((size_t)lv * F + f) * n;
             const float vxp = D[(size_t)y * w + x + 1], vxm = D[(size_t)y * w + x - 1];
             const float vyp = D[(size_t)(y + 1) * w + x], vym = D[(size_t)(y - 1) * w + x];
             const float Dx = 0.5f * (vxp - vxm), Dy = 0.5f * (vyp - vym);
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void k_ov_compact(const float *__restrict__ ca
 // then the 486 comparisons are spread over the 64 lanes.
 __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt, const float *__restrict__ Lx, const float *__restrict__ Ly,
                                                    int h, int w, const Keypoint *__restrict__ kps, const int32_t *__restrict__ nkp,
-                                                   uint8_t *__restrict__ desc, int8_t *__restrict__ bits, int32_t *__restrict__ pop)
+                                                   uint8_t *__restrict__ desc, int8_t *__restrict__ bits, int32_t *__restrict__ pop, int F)
 {
     __shared__ float s_val[29][3];
     __shared__ uint32_t s_words[16];
@@ -487,9 +487,9 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
     }
     const Keypoint kp = kps[(size_t)f * MAXKP + q];
     const size_t npx = (size_t)h * w;
-    const float *T = Lt + ((size_t)f * NLEV + kp.level) * npx;
-    const float *X = Lx + ((size_t)f * NLEV + kp.level) * npx;
-    const float *Y = Ly + ((size_t)f * NLEV + kp.level) * npx;
+    const float *T = Lt + ((size_t)kp.level * F + f) * npx;
+    const float *X = Lx + ((size_t)kp.level * F + f) * npx;
+    const float *Y = Ly + ((size_t)kp.level * F + f) * npx;
     const float sc = (float)D_SSIZE[kp.level];
     if (lane < 16) s_words[lane] = 0;
     if (lane < 29) {
@@ -1203,35 +1203,22 @@ int alloc_work(uwip_ctx *ctx, int F, int h, int w, OvWork *W)
     return UWIP_OK;
 }
 
-// level images are stored [F][NLEV][h][w]; per-level kernels address level lv of every frame through a
-// base pointer + frame stride of NLEV*n.  The simple kernels above index frames densely (stride n), so the
-// per-level passes run on dense scratch planes and are copied into place with a strided 2-D memcpy.
-int put_level(uwip_ctx *ctx, float *dst_levels, const float *dense, int lv, int F, size_t n)
-{
-    UWIP_HIP(ctx, hipMemcpy2DAsync(dst_levels + (size_t)lv * n, sizeof(float) * n * NLEV, dense, sizeof(float) * n, sizeof(float) * n,
-                                   (size_t)F, hipMemcpyDeviceToDevice, ctx->stream));
-    return UWIP_OK;
-}
-
+// Level images are stored level-major, [NLEV][F][h][w]: every level is itself a dense batch, so the per-level
+// kernels write their results in place (no staging copies).
 // detect + describe every frame whose gray/L0 already sit in W (working size h x w)
 int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features *ft, int first_slot)
 {
-    const size_t n = (size_t)h * w;
+    const size_t n = (size_t)h * w, lvl = n * F;
     const dim3 g = grid2d(w, h, F);
-    float *cur = (float *)uwip_ws(ctx, "ov.cur", n * F * 4);
-    float *dLx = (float *)uwip_ws(ctx, "ov.dLx", n * F * 4);
-    float *dLy = (float *)uwip_ws(ctx, "ov.dLy", n * F * 4);
-    float *dLd = (float *)uwip_ws(ctx, "ov.dLd", n * F * 4);
-    if (!cur || !dLx || !dLy || !dLd) return UWIP_ERR_NOMEM;
+    ctx->ov_last_frames = F;
     {
         uwip_kscope ks(ctx, "k_ov_scale_space");
         const ConvK K0 = gauss_kernel(H_SIGMA[0]), K1 = gauss_kernel(1.0f);
         k_ov_conv<true><<<g, 256, 0, ctx->stream>>>(W.L0, W.tmp, h, w, K0);
-        k_ov_conv<false><<<g, 256, 0, ctx->stream>>>(W.tmp, cur, h, w, K0);
+        k_ov_conv<false><<<g, 256, 0, ctx->stream>>>(W.tmp, W.Lt, h, w, K0);
         for (int lv = 0; lv < NLEV; ++lv) {
-            int rc = put_level(ctx, W.Lt, cur, lv, F, n);
-            if (rc) return rc;
-            k_ov_conv<true><<<g, 256, 0, ctx->stream>>>(cur, W.tmp, h, w, K1);
+            float *Lt = W.Lt + lv * lvl;
+            k_ov_conv<true><<<g, 256, 0, ctx->stream>>>(Lt, W.tmp, h, w, K1);
             k_ov_conv<false><<<g, 256, 0, ctx->stream>>>(W.tmp, W.Lsm, h, w, K1);
             if (lv == 0) {
                 UWIP_HIP(ctx, hipMemsetAsync(W.hmax, 0, sizeof(uint32_t) * F, ctx->stream));
@@ -1241,23 +1228,21 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
                 k_ov_kc_final<<<uwip_cdiv(F, 64), 64, 0, ctx->stream>>>(W.hmax, W.khist, W.kc, F);
             }
             const int s = H_SSIZE[lv];
-            k_ov_deriv1<<<g, 256, 0, ctx->stream>>>(W.Lsm, dLx, dLy, h, w, s);
-            k_ov_ldet<<<g, 256, 0, ctx->stream>>>(dLx, dLy, dLd, h, w, s);
-            rc = put_level(ctx, W.Lx, dLx, lv, F, n); if (rc) return rc;
-            rc = put_level(ctx, W.Ly, dLy, lv, F, n); if (rc) return rc;
-            rc = put_level(ctx, W.Ldet, dLd, lv, F, n); if (rc) return rc;
+            k_ov_deriv1<<<g, 256, 0, ctx->stream>>>(W.Lsm, W.Lx + lv * lvl, W.Ly + lv * lvl, h, w, s);
+            k_ov_ldet<<<g, 256, 0, ctx->stream>>>(W.Lx + lv * lvl, W.Ly + lv * lvl, W.Ldet + lv * lvl, h, w, s);
             if (lv + 1 < NLEV) {
                 k_ov_flow<<<g, 256, 0, ctx->stream>>>(W.Lsm, W.kc, W.flow, h, w);
                 const float e0 = 0.5f * H_SIGMA[lv] * H_SIGMA[lv], e1 = 0.5f * H_SIGMA[lv + 1] * H_SIGMA[lv + 1];
                 float taus[32];
                 const int nt = fed_taus(e1 - e0, taus);
-                float *a = cur, *b = W.ping;
+                // ping-pong between Lt[lv+1] and a scratch plane so that the last step lands in Lt[lv+1]
+                float *next = W.Lt + (lv + 1) * lvl;
+                const float *src = Lt;
+                float *dst = (nt & 1) ? next : W.ping;
                 for (int k = 0; k < nt; ++k) {
-                    k_ov_fed<<<g, 256, 0, ctx->stream>>>(a, W.flow, b, h, w, taus[k]);
-                    std::swap(a, b);
-                }
-                if (a != cur) {        // result sits in ping: make `cur` point at it by swapping the workspaces' roles
-                    UWIP_HIP(ctx, hipMemcpyAsync(cur, a, n * F * 4, hipMemcpyDeviceToDevice, ctx->stream));
+                    k_ov_fed<<<g, 256, 0, ctx->stream>>>(src, W.flow, dst, h, w, taus[k]);
+                    src = dst;
+                    dst = (dst == next) ? W.ping : next;
                 }
             }
         }
@@ -1269,7 +1254,7 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
     int32_t *nkp = ft->d_n + first_slot;
     {
         uwip_kscope ks(ctx, "k_ov_detect");
-        k_ov_extrema<<<grid2d(w, h, F * NLEV), 256, 0, ctx->stream>>>(W.Ldet, W.cand, h, w);
+        k_ov_extrema<<<grid2d(w, h, F * NLEV), 256, 0, ctx->stream>>>(W.Ldet, W.cand, h, w, F);
         UWIP_HIP(ctx, hipMemsetAsync(W.selhist, 0, sizeof(uint32_t) * 65536 * F, ctx->stream));
         k_ov_sel_hist<0><<<dim3(64, F), 256, 0, ctx->stream>>>(W.cand, n4, W.selhist, W.sel);
         k_ov_sel_pick<0><<<F, 256, 0, ctx->stream>>>(W.selhist, W.sel);
@@ -1278,7 +1263,7 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
         k_ov_sel_pick<1><<<F, 256, 0, ctx->stream>>>(W.selhist, W.sel);
         k_ov_count<<<dim3(nchunks, F), 256, 0, ctx->stream>>>(W.cand, n4, W.sel, W.counts, nchunks);
         k_ov_scan_chunks<<<F, 256, 0, ctx->stream>>>(W.counts, nchunks, nkp);
-        k_ov_compact<<<dim3(nchunks, F), 256, 0, ctx->stream>>>(W.cand, W.Ldet, h, w, W.sel, W.counts, nchunks, kps);
+        k_ov_compact<<<dim3(nchunks, F), 256, 0, ctx->stream>>>(W.cand, W.Ldet, h, w, W.sel, W.counts, nchunks, kps, F);
         UWIP_HIP(ctx, hipGetLastError());
     }
     {
@@ -1286,7 +1271,7 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
         k_ov_describe<<<dim3(MAXKP, F), 64, 0, ctx->stream>>>(W.Lt, W.Lx, W.Ly, h, w, kps, nkp,
                                                              ft->d_desc + (size_t)first_slot * MAXKP * DESC_BYTES,
                                                              ft->d_bits + (size_t)first_slot * MAXKP * DESC_K,
-                                                             ft->d_pop + (size_t)first_slot * MAXKP);
+                                                             ft->d_pop + (size_t)first_slot * MAXKP, F);
         UWIP_HIP(ctx, hipGetLastError());
     }
     return UWIP_OK;
@@ -1403,7 +1388,8 @@ UWIP_API int uwip_overlap_debug_level(uwip_ctx *ctx, int frame, int level, int r
     float *Lt = get("ov.Lt"), *Lx = get("ov.Lx"), *Ly = get("ov.Ly"), *Ld = get("ov.Ldet"), *kc = get("ov.kc");
     UWIP_REQUIRE(ctx, Lt && Lx && Ly && Ld && kc, "no detect call yet");
     UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const size_t off = ((size_t)frame * NLEV + level) * n;
+    UWIP_REQUIRE(ctx, frame < ctx->ov_last_frames, "frame beyond the last detect batch");
+    const size_t off = ((size_t)level * ctx->ov_last_frames + frame) * n;
     if (h_Lt) UWIP_HIP(ctx, hipMemcpy(h_Lt, Lt + off, n * 4, hipMemcpyDeviceToHost));
     if (h_Lx) UWIP_HIP(ctx, hipMemcpy(h_Lx, Lx + off, n * 4, hipMemcpyDeviceToHost));
     if (h_Ly) UWIP_HIP(ctx, hipMemcpy(h_Ly, Ly + off, n * 4, hipMemcpyDeviceToHost));
@@ -1449,11 +1435,8 @@ UWIP_API int uwip_overlap_match(uwip_ctx *ctx, const uwip_features *fq, const uw
     {
         uwip_kscope ks(ctx, "k_ov_geometry");
         const size_t lds = (size_t)MAXKP * 16 + MAXKP + (size_t)TH * MASK_WORDS * 4 + (size_t)TH * 4;
-        static bool attr_set = false;          // > 64 KiB of dynamic LDS needs an explicit opt-in
-        if (!attr_set) {
-            UWIP_HIP(ctx, hipFuncSetAttribute((const void *)k_ov_geometry, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
+        int rc = uwip_lds_optin(ctx, "k_ov_geometry", (const void *)k_ov_geometry, lds);
+        if (rc) return rc;
         k_ov_geometry<<<npairs, 256, lds, ctx->stream>>>(fq->d_kp, ft->d_kp, fq->d_n, ft->d_n, d_pairs, d_pairs + npairs, m_idx, m_dist,
                                                         fq->w, fq->h, videoWidth, videoHeight, seed, d_ratio, info, d_H);
         UWIP_HIP(ctx, hipGetLastError());

@@ -33,6 +33,9 @@ struct uwip_ctx {
     std::map<std::string, uwip_ws_buf> hs;
     // immutable device tables keyed by their geometry (strip / cell lists)
     std::map<std::string, uwip_ws_buf> tables;
+    // kernels whose > 64 KiB dynamic-LDS opt-in (hipFuncSetAttribute) has been made on this device
+    std::map<std::string, bool> lds_optin;
+    int ov_last_frames = 0;        // batch size of the most recent uwip_overlap_detect (debug taps)
     // profiling
     bool prof = false;
     std::vector<uwip_prof_rec> prof_recs;
@@ -55,6 +58,8 @@ void *uwip_host_ws(uwip_ctx *ctx, const char *name, size_t bytes);  // pinned ho
 const void *uwip_table_find(uwip_ctx *ctx, const std::string &key, size_t *bytes);
 const void *uwip_table_put(uwip_ctx *ctx, const std::string &key, const void *host, size_t bytes);
 int uwip_prof_flush(uwip_ctx *ctx);
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context, kernel)
+int uwip_lds_optin(uwip_ctx *ctx, const char *name, const void *func, size_t bytes);
 
 #define UWIP_HIP(ctx, expr)                                                          \
     do {                                                                             \
