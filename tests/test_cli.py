@@ -123,5 +123,13 @@ def test_videostrip_cli_selector_and_report(tmp_path, orc):
             if eof:
                 break
     assert [(r_[0], r_[1]) for r_ in rows] == exp, (rows, exp)
+    # the Python mirror of the loop (uwimageproc_amd.videostrip.select_keyframes) agrees with the CLI
+    import torch
+    import uwimageproc_amd as uw
+    from uwimageproc_amd import videostrip as vs
+    c = uw.Context(0)
+    got = vs.select_keyframes(c, [torch.from_numpy(f).cuda() for f in frames], minOverlap=p, kWindow=k)
+    assert [(str(a), str(b)) for a, b, _, _ in got] == exp
+    c.close()
     assert len(rows) >= 2 and os.path.exists(prefix + "0000.png") and os.path.exists(prefix + f"{len(rows)-1:04d}.png")
     assert np.array_equal(_load_png(prefix + "0000.png"), frames[0])

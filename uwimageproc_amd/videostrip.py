@@ -125,3 +125,55 @@ def calcBlur(ctx: Context, frame: torch.Tensor):
     ctx.call("uwip_calcBlur", C.byref(b), C.c_void_p(out.data_ptr()))
     ctx.sync()
     return float(out.cpu()[0]) if frame.dim() == 3 else out
+
+
+def select_keyframes(ctx: Context, frames, minOverlap: float = OVERLAP_MIN, kWindow: int = DEFAULT_KWINDOW, seed: int = 1,
+                     report=None):
+    """The selector loop of src/main.cpp:284-394 over a sequence of full-resolution BGR frames (CUDA uint8
+    tensors): first frame = key frame; a frame whose overlap with the key frame is <= minOverlap (or that
+    yields -2.0 -> OVERLAP_MIN + 0.01, :321-326) triggers the sharpest-of-the-next-k refinement (:335-366).
+    Returns the exported rows [(id, frame_number, overlap, blur)], the same columns as the reference's TSV
+    report (:263,297,381).  Ends when the frames run out (the reference exits there, B-14)."""
+    global videoWidth, videoHeight
+    frames = list(frames)
+    if not frames:
+        return []
+    videoHeight, videoWidth = int(frames[0].shape[0]), int(frames[0].shape[1])
+    h = int(round(videoHeight * (TARGET_WIDTH / videoWidth)))
+    w = int(round(videoWidth * (TARGET_WIDTH / videoWidth)))
+
+    def resized(f):          # cv::resize(frame, res, Size(), f, f) only matters for calcBlur: identity when already 640 wide
+        if f.shape[1] == w and f.shape[0] == h:
+            return f
+        import torch.nn.functional as F_
+        t = F_.interpolate(f.permute(2, 0, 1)[None].float(), size=(h, w), mode="bilinear", align_corners=False)
+        return t[0].permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).contiguous()
+
+    rows = [(0, 0, 0.0, 0.0)]
+    kf = keyframe(ctx, frames[0])
+    nxt, read = 1, 1
+    while nxt < len(frames):
+        f = frames[nxt]; nxt += 1; read += 1
+        ov = calcOverlap(ctx, kf, f, seed)
+        if ov == -2.0:
+            ov = OVERLAP_MIN + 0.01
+        if ov <= minOverlap:
+            best, bestn, bf = calcBlur(ctx, resized(f)), nxt - 1, f
+            eof = False
+            for _ in range(kWindow):
+                if nxt >= len(frames):
+                    eof = True
+                    break
+                g = frames[nxt]; nxt += 1; read += 1
+                b = calcBlur(ctx, resized(g))
+                if b > best:
+                    best, bestn, bf = b, read, g
+            kf.feats.close()
+            kf = keyframe(ctx, bf)
+            rows.append((len(rows), bestn, float(ov), float(best)))
+            if report is not None:
+                report.write(f"{rows[-1][0]}\t{bestn}\t\t{ov}\t{best}\n")
+            if eof:
+                break
+    kf.feats.close()
+    return rows
