@@ -121,7 +121,7 @@ def main():
     Fs = F // S
     # a few distinct synthetic frames, tiled to the batch (seed = 1234 + index)
     distinct = min(F, 8)
-    base = synth.uw_stream(rank * 100, distinct, H, W)
+    base = synth.uw_stream(0, distinct, H, W, seed0=1234 + 1000 * rank)      # a different scene per rank, same size
     reps = (F + distinct - 1) // distinct
     src = torch.from_numpy(np.concatenate([base] * reps, axis=0)[:F]).to(dev)
     torch.cuda.synchronize()
