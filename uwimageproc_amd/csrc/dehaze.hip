@@ -18,6 +18,7 @@
 #include "uwip_internal.hpp"
 #include "device_utils.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 namespace {
@@ -378,41 +379,14 @@ constexpr int HSEG = 256;
 //  2. TPP = 256 / NPL threads own one plane each: a thread reads its contiguous run into registers,
 //     scans it there, publishes the run total, and after one barrier writes run + offset back.
 constexpr int RUNMAX = 24;
+// In-place inclusive prefix scan of NI uint32 rows and NF float64 rows of LW entries already in LDS.
+// TPP = 256 / (NI + NF) threads own one row each; a thread scans its contiguous run in registers, publishes the
+// run total and, after ONE barrier common to all lanes, writes run + offset back.  Ends with a barrier.
 template <int NI, int NF>
-__device__ __forceinline__ void load_scan(uint32_t *si /*[NI][LW]*/, double *sf /*[NF][LW]*/, double *s_tot /*[(NI+NF)][64]*/,
-                                          int LW, const uint32_t *const *iplanes, const double *const (&fplanes)[NF],
-                                          size_t row_off, int x0, int r, int W)
+__device__ __forceinline__ void scan_planes(uint32_t *si, double *sf, double *s_tot, int LW)
 {
     constexpr int NPL = NI + NF;
     constexpr int TPP = 256 / NPL;
-    {
-        uint32_t vi[NI > 0 ? NI : 1][2];
-        double vf[NF][2];
-        const int j0 = threadIdx.x, j1 = threadIdx.x + 256;
-        const int xa = x0 - r - 1 + j0, xb = x0 - r - 1 + j1;
-        const bool oka = xa >= 0 && xa < W, okb = j1 < LW && xb >= 0 && xb < W;
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            vi[k][0] = oka ? iplanes[k][row_off + xa] : 0u;
-            vi[k][1] = okb ? iplanes[k][row_off + xb] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < NF; ++k) {
-            vf[k][0] = oka ? fplanes[k][row_off + xa] : 0.0;
-            vf[k][1] = okb ? fplanes[k][row_off + xb] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            si[(size_t)k * LW + j0] = vi[k][0];
-            if (j1 < LW) si[(size_t)k * LW + j1] = vi[k][1];
-        }
-#pragma unroll
-        for (int k = 0; k < NF; ++k) {
-            sf[(size_t)k * LW + j0] = vf[k][0];
-            if (j1 < LW) sf[(size_t)k * LW + j1] = vf[k][1];
-        }
-    }
-    __syncthreads();
     const int k = threadIdx.x / TPP, t = threadIdx.x - k * TPP;
     const int run = (LW + TPP - 1) / TPP;
     const int a = t * run, e = min(a + run, LW);
@@ -448,6 +422,42 @@ __device__ __forceinline__ void load_scan(uint32_t *si /*[NI][LW]*/, double *sf 
         for (int i = 0; i < RUNMAX; ++i) if (a + i < e) frow[a + i] = vf[i] + off;
     }
     __syncthreads();
+}
+
+template <int NI, int NF>
+__device__ __forceinline__ void load_scan(uint32_t *si /*[NI][LW]*/, double *sf /*[NF][LW]*/, double *s_tot /*[(NI+NF)][64]*/,
+                                          int LW, const uint32_t *const *iplanes, const double *const (&fplanes)[NF],
+                                          size_t row_off, int x0, int r, int W)
+{
+    {
+        uint32_t vi[NI > 0 ? NI : 1][2];
+        double vf[NF][2];
+        const int j0 = threadIdx.x, j1 = threadIdx.x + 256;
+        const int xa = x0 - r - 1 + j0, xb = x0 - r - 1 + j1;
+        const bool oka = xa >= 0 && xa < W, okb = j1 < LW && xb >= 0 && xb < W;
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            vi[k][0] = oka ? iplanes[k][row_off + xa] : 0u;
+            vi[k][1] = okb ? iplanes[k][row_off + xb] : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            vf[k][0] = oka ? fplanes[k][row_off + xa] : 0.0;
+            vf[k][1] = okb ? fplanes[k][row_off + xb] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NI; ++k) {
+            si[(size_t)k * LW + j0] = vi[k][0];
+            if (j1 < LW) si[(size_t)k * LW + j1] = vi[k][1];
+        }
+#pragma unroll
+        for (int k = 0; k < NF; ++k) {
+            sf[(size_t)k * LW + j0] = vf[k][0];
+            if (j1 < LW) sf[(size_t)k * LW + j1] = vf[k][1];
+        }
+    }
+    __syncthreads();
+    scan_planes<NI, NF>(si, sf, s_tot, LW);
 }
 
 // window sum over columns [max(x-r,0), min(x+r,W-1)] from the scanned row
@@ -549,6 +559,160 @@ __global__ __launch_bounds__(256) void k_gf_final_h(const double *__restrict__ V
         const double a0 = win(sr, x, x0, r, W), a1 = win(sr + LW, x, x0, r, W);
         const double a2 = win(sr + 2 * (size_t)LW, x, x0, r, W), bb = win(sr + 3 * (size_t)LW, x, x0, r, W);
         Q[((size_t)f * NP + ip) * n + (size_t)y * W + x] = (a0 * I0 + a1 * I1 + a2 * I2 + bb) * rbase;
+    }
+}
+
+// ---- streaming strip form of the guided filter ------------------------------------------------------
+// A block owns a strip of 256 columns (TS = 256 - 2r outputs plus an r-column halo on each side) and walks
+// down the rows.  Every thread keeps the vertical sliding-window sums of its own column in registers; for each
+// row the 256 column sums of every plane go to LDS, are prefix-scanned across the strip, and the interior
+// columns take their box sums as differences, solve, and write a, b (or q).  The 13-17 intermediate
+// box-sum planes of the separable form never exist in HBM.  Columns outside the image contribute zeros, which
+// is exactly the reference's "valid part of the window" (guidedfilter.py:39-41,67).
+template <int NP>
+__global__ __launch_bounds__(256) void k_gf_strip_solve(const uint8_t *__restrict__ guide, size_t step, size_t fs,
+                                                        const int *__restrict__ gnorm, int gnorm_stride,
+                                                        const double *__restrict__ P /*[F][NP][H][W]*/,
+                                                        double *__restrict__ AB /*[F*NP][4][H][W]*/, int H, int W, int r,
+                                                        double eps, int TS, int rows_per_chunk)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    constexpr int NF = 4 * NP;
+    double *sf = s_dyn;                                                     // [NF][256]
+    uint32_t *si = reinterpret_cast<uint32_t *>(s_dyn + (size_t)NF * 256);  // [9][256]
+    __shared__ double s_tot[(9 + NF) * 64];
+    __shared__ double s_T[256];
+    const int t = threadIdx.x, f = blockIdx.z;
+    const int x = (int)blockIdx.x * TS - r + t;
+    const bool inimg = x >= 0 && x < W;
+    const size_t n = (size_t)H * W;
+    const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
+    s_T[t] = t >= mn ? normv(t, mn, mx) : 0.0;
+    __syncthreads();
+    const uint8_t *g = guide + (size_t)f * fs + (size_t)(inimg ? x : 0) * 3;
+    const double *pin = P + (size_t)f * NP * n + (inimg ? x : 0);
+    uint32_t gi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double pf[NP][4];
+#pragma unroll
+    for (int ip = 0; ip < NP; ++ip) { pf[ip][0] = pf[ip][1] = pf[ip][2] = pf[ip][3] = 0.0; }
+    auto accum = [&](int yy, bool add) {
+        if (!inimg) return;
+        const uint8_t *p = g + (size_t)yy * step;
+        const uint32_t a = (uint32_t)max((int)p[0] - mn, 0), b = (uint32_t)max((int)p[1] - mn, 0), c = (uint32_t)max((int)p[2] - mn, 0);
+        const uint32_t v[9] = {a, b, c, a * a, a * b, a * c, b * b, b * c, c * c};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gi[k] = add ? gi[k] + v[k] : gi[k] - v[k];
+        const double Ta = s_T[p[0]], Tb = s_T[p[1]], Tc = s_T[p[2]];
+        const double sign = add ? 1.0 : -1.0;
+#pragma unroll
+        for (int ip = 0; ip < NP; ++ip) {
+            const double pv = pin[(size_t)ip * n + (size_t)yy * W];
+            pf[ip][0] += sign * pv; pf[ip][1] += sign * (Ta * pv); pf[ip][2] += sign * (Tb * pv); pf[ip][3] += sign * (Tc * pv);
+        }
+    };
+    const int y0 = blockIdx.y * rows_per_chunk, y1 = min(H, y0 + rows_per_chunk);
+    for (int yy = max(0, y0 - r); yy <= min(H - 1, y0 + r); ++yy) accum(yy, true);
+    const double rdd = 1.0 / (double)(mx - mn);
+    const bool interior = t >= r && t < r + TS && inimg;
+    for (int y = y0; y < y1; ++y) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) si[k * 256 + t] = gi[k];
+#pragma unroll
+        for (int ip = 0; ip < NP; ++ip)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sf[(ip * 4 + k) * 256 + t] = pf[ip][k];
+        __syncthreads();
+        scan_planes<9, NF>(si, sf, s_tot, 256);
+        if (interior) {
+            // window = strip columns [t-r, t+r]; columns outside the image hold zeros
+            const int hi = t + r, lo = t - r - 1;
+            const double rbase = 1.0 / box_base(y, x, H, W, r);
+            const double r1 = rdd * rbase, r2 = (rdd * rdd) * rbase;
+            double gs[9];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const uint32_t wsum = si[k * 256 + hi] - (lo >= 0 ? si[k * 256 + lo] : 0u);
+                gs[k] = (double)wsum * (k < 3 ? r1 : r2);
+            }
+            const double m0 = gs[0], m1 = gs[1], m2 = gs[2];
+            const double s00 = gs[3] - m0 * m0 + eps, s01 = gs[4] - m0 * m1, s02 = gs[5] - m0 * m2;
+            const double s11 = gs[6] - m1 * m1 + eps, s12 = gs[7] - m1 * m2, s22 = gs[8] - m2 * m2 + eps;
+            const double k00 = s11 * s22 - s12 * s12, k01 = s02 * s12 - s01 * s22, k02 = s01 * s12 - s02 * s11;
+            const double k11 = s00 * s22 - s02 * s02, k12 = s01 * s02 - s00 * s12, k22 = s00 * s11 - s01 * s01;
+            const double rdet = 1.0 / (s00 * k00 + s01 * k01 + s02 * k02);
+            const size_t i = (size_t)y * W + x;
+#pragma unroll
+            for (int ip = 0; ip < NP; ++ip) {
+                double w4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    w4[k] = (sf[(ip * 4 + k) * 256 + hi] - (lo >= 0 ? sf[(ip * 4 + k) * 256 + lo] : 0.0)) * rbase;
+                const double mp = w4[0], c0 = w4[1] - m0 * mp, c1 = w4[2] - m1 * mp, c2 = w4[3] - m2 * mp;
+                const double a0 = (c0 * k00 + c1 * k01 + c2 * k02) * rdet;
+                const double a1 = (c0 * k01 + c1 * k11 + c2 * k12) * rdet;
+                const double a2 = (c0 * k02 + c1 * k12 + c2 * k22) * rdet;
+                double *o = AB + ((size_t)f * NP + ip) * 4 * n;
+                o[i] = a0; o[n + i] = a1; o[2 * n + i] = a2;
+                o[3 * n + i] = mp - a0 * m0 - a1 * m1 - a2 * m2;
+            }
+        }
+        __syncthreads();
+        if (y + r + 1 < H) accum(y + r + 1, true);
+        if (y - r >= 0) accum(y - r, false);
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_gf_strip_final(const double *__restrict__ AB /*[F*NP][4][H][W]*/,
+                                                        const uint8_t *__restrict__ guide, size_t step, size_t fs,
+                                                        const int *__restrict__ gnorm, int gnorm_stride,
+                                                        double *__restrict__ Q /*[F*NP][H][W]*/, int H, int W, int r, int TS,
+                                                        int rows_per_chunk)
+{
+    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
+    constexpr int NF = 4 * NP;
+    double *sf = s_dyn;                                                     // [NF][256]
+    __shared__ double s_tot[NF * 64];
+    const int t = threadIdx.x, f = blockIdx.z;
+    const int x = (int)blockIdx.x * TS - r + t;
+    const bool inimg = x >= 0 && x < W;
+    const size_t n = (size_t)H * W;
+    const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
+    const double *ab = AB + (size_t)f * NF * n + (inimg ? x : 0);
+    double acc[NF];
+#pragma unroll
+    for (int k = 0; k < NF; ++k) acc[k] = 0.0;
+    auto accum = [&](int yy, double sign) {
+        if (!inimg) return;
+#pragma unroll
+        for (int k = 0; k < NF; ++k) acc[k] += sign * ab[(size_t)k * n + (size_t)yy * W];
+    };
+    const int y0 = blockIdx.y * rows_per_chunk, y1 = min(H, y0 + rows_per_chunk);
+    for (int yy = max(0, y0 - r); yy <= min(H - 1, y0 + r); ++yy) accum(yy, 1.0);
+    const bool interior = t >= r && t < r + TS && inimg;
+    const uint8_t *gb = guide + (size_t)f * fs + (size_t)(inimg ? x : 0) * 3;
+    for (int y = y0; y < y1; ++y) {
+#pragma unroll
+        for (int k = 0; k < NF; ++k) sf[k * 256 + t] = acc[k];
+        __syncthreads();
+        scan_planes<0, NF>(nullptr, sf, s_tot, 256);
+        if (interior) {
+            const int hi = t + r, lo = t - r - 1;
+            const double rbase = 1.0 / box_base(y, x, H, W, r);
+            const uint8_t *p = gb + (size_t)y * step;
+            const double I0 = normv(p[0], mn, mx), I1 = normv(p[1], mn, mx), I2 = normv(p[2], mn, mx);
+#pragma unroll
+            for (int ip = 0; ip < NP; ++ip) {
+                double w4[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    w4[k] = sf[(ip * 4 + k) * 256 + hi] - (lo >= 0 ? sf[(ip * 4 + k) * 256 + lo] : 0.0);
+                Q[((size_t)f * NP + ip) * n + (size_t)y * W + x] = (w4[0] * I0 + w4[1] * I1 + w4[2] * I2 + w4[3]) * rbase;
+            }
+        }
+        __syncthreads();
+        if (y + r + 1 < H) accum(y + r + 1, 1.0);
+        if (y - r >= 0) accum(y - r, -1.0);
     }
 }
 
@@ -846,6 +1010,31 @@ int guided_filter_u8(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs
     auto rpc_for = [&](int zcount) { const int c = chunks_for(zcount); return (H + c - 1) / c; };
     const unsigned xb = uwip_cdiv(W, 256);
     UWIP_REQUIRE(ctx, np == 1 || np == 2, "np must be 1 or 2");
+    UWIP_REQUIRE(ctx, H <= 65535 && F <= 65535, "too many rows/frames for one launch");
+    const char *env_strip = getenv("UWIP_GF_STRIP");
+    const int strip_mode = env_strip ? atoi(env_strip) : 4;   // 0 = separable form (box-sum planes in HBM)
+    if (strip_mode > 0 && 2 * r < 200) {
+        // streaming strip form: two kernels, no intermediate box-sum planes
+        const int TS = 256 - 2 * r;
+        const int nchunk = std::max(1, std::min(strip_mode, std::max(1, H / 64)));
+        const int rpc = (H + nchunk - 1) / nchunk;
+        const dim3 gs(uwip_cdiv(W, TS), uwip_cdiv(H, rpc), (unsigned)F);
+        UWIP_REQUIRE(ctx, (uint64_t)256 * (2 * r + 1) * 65025ull < (1ull << 32), "window too large for the exact integer guide sums");
+        {
+            uwip_kscope ks(ctx, "k_gf_strip_solve");
+            const size_t lds = (size_t)(4 * np) * 256 * sizeof(double) + (size_t)9 * 256 * sizeof(uint32_t);
+            if (np == 2) k_gf_strip_solve<2><<<gs, 256, lds, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc);
+            else k_gf_strip_solve<1><<<gs, 256, lds, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc);
+        }
+        {
+            uwip_kscope ks(ctx, "k_gf_strip_final");
+            const size_t lds = (size_t)(4 * np) * 256 * sizeof(double);
+            if (np == 2) k_gf_strip_final<2><<<gs, 256, lds, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, Q, H, W, r, TS, rpc);
+            else k_gf_strip_final<1><<<gs, 256, lds, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, Q, H, W, r, TS, rpc);
+        }
+        UWIP_HIP(ctx, hipGetLastError());
+        return UWIP_OK;
+    }
     const int LW = HSEG + 2 * r + 1;
     const size_t lds_solve = (size_t)(4 * np) * LW * sizeof(double) + (size_t)9 * LW * sizeof(uint32_t);
     const size_t lds_final = (size_t)(4 * np) * LW * sizeof(double);
