@@ -1012,7 +1012,11 @@ int guided_filter_u8(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs
     UWIP_REQUIRE(ctx, np == 1 || np == 2, "np must be 1 or 2");
     UWIP_REQUIRE(ctx, H <= 65535 && F <= 65535, "too many rows/frames for one launch");
     const char *env_strip = getenv("UWIP_GF_STRIP");
-    const int strip_mode = env_strip ? atoi(env_strip) : 4;   // 0 = separable form (box-sum planes in HBM)
+    // UWIP_GF_STRIP: unset / "ws" = wave-strip kernels (guided_filter_ws.hip), N > 0 = block-strip kernels with N row
+    // chunks, 0 = separable form (box-sum planes in HBM; the only form for 2r > 192)
+    if ((!env_strip || env_strip[0] == 'w') && 2 * r <= 192)
+        return uwip_gf_wave_strip(ctx, guide, step, fs, gnorm, gstride, P, Q, AB, F, np, H, W, r, eps);
+    const int strip_mode = env_strip ? atoi(env_strip) : 0;
     if (strip_mode > 0 && 2 * r < 200) {
         // streaming strip form: two kernels, no intermediate box-sum planes
         const int TS = 256 - 2 * r;

@@ -1,0 +1,499 @@
+// Guided filter (guidedfilter.py:6-110 of the reference, colour guide, radius r) as two streaming
+// "wave-strip" kernels for gfx950.
+//
+// One wavefront owns a strip of 256 image columns -- four adjacent columns per lane, TS = 256 - 2r of them
+// outputs and r columns of halo on each side -- and walks down a chunk of rows:
+//   * the vertical box sums are sliding-window accumulators in registers (one add row, one subtract row per
+//     step, both prefetched while the previous row is being finished);
+//   * the horizontal box sums come from an inclusive prefix over the strip: a 4-column serial prefix per lane,
+//     a DPP scan of the lane totals across the wave (no LDS, no barrier), the prefix row parked in LDS once,
+//     and every output column taking  G[x+r] - G[x-r-1];
+//   * k_gf_ws_solve inverts the 3x3 (cov(I) + eps) per pixel and writes a (3 planes) and b; k_gf_ws_final
+//     box-filters a, b the same way and writes q = mean_a . I + mean_b.
+// A block is a single wave, so there is no workgroup barrier anywhere; the LDS row is private to the wave and
+// LDS operations of one wave execute in order.  Columns outside the image contribute zeros and every mean
+// divides by the analytic in-image window size, as guidedfilter.py:39-41,67 does.
+//
+// The guide statistics are exact: with I = (v - mn) / (mx - mn) for 8-bit v, the window sums of I and I*I' are
+// uint32 sums of (v - mn) and (v - mn)(v' - mn) scaled once by 1/(mx-mn) and 1/(mx-mn)^2.  The sums that involve
+// p are float64 sums of (v - mn) * p scaled by 1/(mx-mn) afterwards.  Float64 throughout; FMA contraction is
+// allowed in this file (the result is checked against the reference at 1e-9, tests/test_dehaze_gpu.py).
+#include "uwip_internal.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, true);
+}
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp0(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = dpp0<CTRL, ROWMASK>((uint32_t)b), hi = dpp0<CTRL, ROWMASK>((uint32_t)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// inclusive prefix over the 64 lanes: Hillis-Steele inside each row of 16 lanes (row_shr 1,2,4,8), then
+// row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3; lanes without a source read 0
+template <class T>
+__device__ __forceinline__ T wave_incl(T v)
+{
+    v += dpp0<0x111, 0xf>(v);
+    v += dpp0<0x112, 0xf>(v);
+    v += dpp0<0x114, 0xf>(v);
+    v += dpp0<0x118, 0xf>(v);
+    v += dpp0<0x142, 0xa>(v);
+    v += dpp0<0x143, 0xc>(v);
+    return v;
+}
+// exclusive prefix: shift the wave by one lane (wave_shr:1), then the inclusive scan
+template <class T>
+__device__ __forceinline__ T wave_excl(T v) { return wave_incl(dpp0<0x138, 0xf>(v)); }
+
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int byte_of(const uint32_t (&g)[3], int k) { return (int)((g[k >> 2] >> ((k & 3) * 8)) & 0xffu); }
+
+struct StripGeom {
+    int l, x0;           // lane, image column of the lane's first column
+    bool in[4];          // column inside the image
+    bool act[4];         // column is an output column of this strip
+    int ah[4], al[4];    // LDS slots (j * 64 + lane) of G[c + r] and G[c - r - 1]
+    bool lo_ok[4];       // c - r - 1 >= 0 (else G = 0)
+    __device__ __forceinline__ void init(int bx, int TS, int r, int W)
+    {
+        l = threadIdx.x;
+        x0 = bx * TS - r + 4 * l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = 4 * l + j, x = x0 + j;
+            in[j] = x >= 0 && x < W;
+            act[j] = c >= r && c < r + TS && x < W;
+            const int h = min(c + r, 255), lo = c - r - 1;
+            lo_ok[j] = lo >= 0;
+            const int lc = max(lo, 0);
+            ah[j] = (h & 3) * 64 + (h >> 2);
+            al[j] = (lc & 3) * 64 + (lc >> 2);
+        }
+    }
+};
+
+__device__ __forceinline__ double count_of(int lo, int hi, int n) { return (double)(min(hi, n - 1) - max(lo, 0) + 1); }
+
+// ---- a, b ---------------------------------------------------------------------------------------------
+template <int NP>
+struct SolveRow {
+    uint32_t g[3];      // 4 columns x 3 bytes of the guide
+    double p[NP][4];
+};
+
+template <int NP, bool VEC>
+__global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ guide, size_t step, size_t fs,
+                                                    const int *__restrict__ gnorm, int gnorm_stride,
+                                                    const double *__restrict__ P /*[F][NP][H][W]*/,
+                                                    double *__restrict__ AB /*[F*NP][4][H][W]*/, int H, int W, int r, double eps,
+                                                    int TS, int rpc)
+{
+#pragma clang fp contract(fast)
+    __shared__ uint4 s_u4[2 * 4 * 64];
+    __shared__ uint32_t s_u1[4 * 64];
+    __shared__ double2 s_d2[NP * 2 * 4 * 64];
+    StripGeom sg;
+    sg.init(blockIdx.x, TS, r, W);
+    const int l = sg.l, f = blockIdx.z;
+    const size_t n = (size_t)H * W;
+    const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
+    const uint32_t fillw = (uint32_t)mn * 0x01010101u;
+    const uint8_t *gf = guide + (size_t)f * fs;
+    const double *pin = P + (size_t)f * NP * n;
+
+    uint32_t gi[4][9];
+    double pf[4][NP][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) gi[j][k] = 0u;
+#pragma unroll
+        for (int ip = 0; ip < NP; ++ip) pf[j][ip][0] = pf[j][ip][1] = pf[j][ip][2] = pf[j][ip][3] = 0.0;
+    }
+
+    auto load_row = [&](int yy, SolveRow<NP> &R) {
+        R.g[0] = R.g[1] = R.g[2] = fillw;
+#pragma unroll
+        for (int ip = 0; ip < NP; ++ip) R.p[ip][0] = R.p[ip][1] = R.p[ip][2] = R.p[ip][3] = 0.0;
+        if (yy < 0) return;
+        if (VEC) {
+            if (sg.in[0]) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(gf + (size_t)yy * step + (size_t)sg.x0 * 3);
+                R.g[0] = q[0]; R.g[1] = q[1]; R.g[2] = q[2];
+#pragma unroll
+                for (int ip = 0; ip < NP; ++ip) {
+                    const double2 *pp = reinterpret_cast<const double2 *>(pin + (size_t)ip * n + (size_t)yy * W + sg.x0);
+                    const double2 u = pp[0], v = pp[1];
+                    R.p[ip][0] = u.x; R.p[ip][1] = u.y; R.p[ip][2] = v.x; R.p[ip][3] = v.y;
+                }
+            }
+        } else {
+            uint32_t b[12];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint8_t *q = gf + (size_t)yy * step + (size_t)(sg.in[j] ? sg.x0 + j : 0) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) b[3 * j + c] = sg.in[j] ? (uint32_t)q[c] : (uint32_t)mn;
+#pragma unroll
+                for (int ip = 0; ip < NP; ++ip)
+                    R.p[ip][j] = sg.in[j] ? pin[(size_t)ip * n + (size_t)yy * W + sg.x0 + j] : 0.0;
+            }
+#pragma unroll
+            for (int w = 0; w < 3; ++w) R.g[w] = b[4 * w] | (b[4 * w + 1] << 8) | (b[4 * w + 2] << 16) | (b[4 * w + 3] << 24);
+        }
+    };
+    auto accum = [&](const SolveRow<NP> &R, auto add_tag) {
+        constexpr bool ADD = decltype(add_tag)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t a = (uint32_t)max(byte_of(R.g, 3 * j) - mn, 0), b = (uint32_t)max(byte_of(R.g, 3 * j + 1) - mn, 0),
+                           c = (uint32_t)max(byte_of(R.g, 3 * j + 2) - mn, 0);
+            const uint32_t v[9] = {a, b, c, a * a, a * b, a * c, b * b, b * c, c * c};
+#pragma unroll
+            for (int k = 0; k < 9; ++k) gi[j][k] = ADD ? gi[j][k] + v[k] : gi[j][k] - v[k];
+            const double da = (double)a, db = (double)b, dc = (double)c;
+#pragma unroll
+            for (int ip = 0; ip < NP; ++ip) {
+                const double pv = ADD ? R.p[ip][j] : -R.p[ip][j];
+                pf[j][ip][0] += pv; pf[j][ip][1] += da * pv; pf[j][ip][2] += db * pv; pf[j][ip][3] += dc * pv;
+            }
+        }
+    };
+    const std::true_type ADD{};
+    const std::false_type SUB{};
+
+    const int y0 = blockIdx.y * rpc, y1 = min(H, y0 + rpc);
+    const double rdd = 1.0 / (double)(mx - mn);
+    // warm-up: rows [max(0, y0 - r), y0 + r) in batches of four loads
+    int v = max(y0 - r, 0);
+    const int wend = min(y0 + r, H);   // first row that belongs to the steady loop
+    for (; v < wend; v += 4) {
+        SolveRow<NP> R0, R1, R2, R3;
+        load_row(v, R0);
+        load_row(v + 1 < wend ? v + 1 : -1, R1);
+        load_row(v + 2 < wend ? v + 2 : -1, R2);
+        load_row(v + 3 < wend ? v + 3 : -1, R3);
+        accum(R0, ADD); accum(R1, ADD); accum(R2, ADD); accum(R3, ADD);
+    }
+    SolveRow<NP> Ra, Rs;
+    load_row(y0 + r < H ? y0 + r : -1, Ra);
+    load_row(-1, Rs);
+    for (int y = y0; y < y1; ++y) {
+        // rows [y - r, y + r]: add y + r, drop y - r - 1 (only rows this block added itself)
+        accum(Ra, ADD);
+        if (y > y0 && y - r - 1 >= 0) accum(Rs, SUB);
+        load_row(y + 1 + r < H ? y + 1 + r : -1, Ra);
+        load_row((y + 1 > y0 && y - r >= 0) ? y - r : -1, Rs);
+
+        // ---- horizontal prefix of the nine guide planes
+        {
+            uint32_t G[9][4];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const uint32_t s0 = gi[0][k], s1 = s0 + gi[1][k], s2 = s1 + gi[2][k], s3 = s2 + gi[3][k];
+                const uint32_t e = wave_incl(s3) - s3;
+                G[k][0] = e + s0; G[k][1] = e + s1; G[k][2] = e + s2; G[k][3] = e + s3;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s_u4[(0 * 4 + j) * 64 + l] = make_uint4(G[0][j], G[1][j], G[2][j], G[3][j]);
+                s_u4[(1 * 4 + j) * 64 + l] = make_uint4(G[4][j], G[5][j], G[6][j], G[7][j]);
+                s_u1[j * 64 + l] = G[8][j];
+            }
+        }
+        // ---- and of the 4 NP float64 planes
+#pragma unroll
+        for (int ip = 0; ip < NP; ++ip) {
+            double D[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double s0 = pf[0][ip][k], s1 = s0 + pf[1][ip][k], s2 = s1 + pf[2][ip][k], s3 = s2 + pf[3][ip][k];
+                const double e = wave_excl(s3);
+                D[k][0] = e + s0; D[k][1] = e + s1; D[k][2] = e + s2; D[k][3] = e + s3;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s_d2[((ip * 2 + 0) * 4 + j) * 64 + l] = make_double2(D[0][j], D[1][j]);
+                s_d2[((ip * 2 + 1) * 4 + j) * 64 + l] = make_double2(D[2][j], D[3][j]);
+            }
+        }
+        wave_lds_fence();
+
+        const double cy = count_of(y - r, y + r, H);
+#pragma unroll
+        for (int jj = 0; jj < 4; jj += 2) {
+            double out[2][NP][4];
+#pragma unroll
+            for (int j2 = 0; j2 < 2; ++j2) {
+                const int j = jj + j2;
+                if (sg.act[j]) {
+                    const int x = sg.x0 + j;
+                    const double rbase = 1.0 / (cy * count_of(x - r, x + r, W));
+                    const double r1 = rdd * rbase, r2 = (rdd * rdd) * rbase;
+                    uint32_t w9[9];
+                    {
+                        const uint4 h0 = s_u4[0 * 256 + sg.ah[j]], h1 = s_u4[1 * 256 + sg.ah[j]];
+                        const uint32_t h2 = s_u1[sg.ah[j]];
+                        uint4 l0 = s_u4[0 * 256 + sg.al[j]], l1 = s_u4[1 * 256 + sg.al[j]];
+                        uint32_t l2 = s_u1[sg.al[j]];
+                        if (!sg.lo_ok[j]) { l0 = make_uint4(0, 0, 0, 0); l1 = l0; l2 = 0u; }
+                        w9[0] = h0.x - l0.x; w9[1] = h0.y - l0.y; w9[2] = h0.z - l0.z; w9[3] = h0.w - l0.w;
+                        w9[4] = h1.x - l1.x; w9[5] = h1.y - l1.y; w9[6] = h1.z - l1.z; w9[7] = h1.w - l1.w;
+                        w9[8] = h2 - l2;
+                    }
+                    const double m0 = (double)w9[0] * r1, m1 = (double)w9[1] * r1, m2 = (double)w9[2] * r1;
+                    const double s00 = (double)w9[3] * r2 - m0 * m0 + eps, s01 = (double)w9[4] * r2 - m0 * m1,
+                                 s02 = (double)w9[5] * r2 - m0 * m2, s11 = (double)w9[6] * r2 - m1 * m1 + eps,
+                                 s12 = (double)w9[7] * r2 - m1 * m2, s22 = (double)w9[8] * r2 - m2 * m2 + eps;
+                    const double k00 = s11 * s22 - s12 * s12, k01 = s02 * s12 - s01 * s22, k02 = s01 * s12 - s02 * s11;
+                    const double k11 = s00 * s22 - s02 * s02, k12 = s01 * s02 - s00 * s12, k22 = s00 * s11 - s01 * s01;
+                    const double rdet = 1.0 / (s00 * k00 + s01 * k01 + s02 * k02);
+#pragma unroll
+                    for (int ip = 0; ip < NP; ++ip) {
+                        const double2 hA = s_d2[(ip * 2 + 0) * 256 + sg.ah[j]], hB = s_d2[(ip * 2 + 1) * 256 + sg.ah[j]];
+                        double2 lA = s_d2[(ip * 2 + 0) * 256 + sg.al[j]], lB = s_d2[(ip * 2 + 1) * 256 + sg.al[j]];
+                        if (!sg.lo_ok[j]) { lA = make_double2(0.0, 0.0); lB = lA; }
+                        const double mp = (hA.x - lA.x) * rbase;
+                        const double c0 = (hA.y - lA.y) * r1 - m0 * mp, c1 = (hB.x - lB.x) * r1 - m1 * mp,
+                                     c2 = (hB.y - lB.y) * r1 - m2 * mp;
+                        const double a0 = (c0 * k00 + c1 * k01 + c2 * k02) * rdet;
+                        const double a1 = (c0 * k01 + c1 * k11 + c2 * k12) * rdet;
+                        const double a2 = (c0 * k02 + c1 * k12 + c2 * k22) * rdet;
+                        out[j2][ip][0] = a0; out[j2][ip][1] = a1; out[j2][ip][2] = a2;
+                        out[j2][ip][3] = mp - a0 * m0 - a1 * m1 - a2 * m2;
+                    }
+                }
+            }
+            const size_t i = (size_t)y * W + sg.x0 + jj;
+#pragma unroll
+            for (int ip = 0; ip < NP; ++ip) {
+                double *o = AB + ((size_t)f * NP + ip) * 4 * n + i;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (VEC) {
+                        if (sg.act[jj]) *reinterpret_cast<double2 *>(o + (size_t)q * n) = make_double2(out[0][ip][q], out[1][ip][q]);
+                    } else {
+                        if (sg.act[jj]) o[(size_t)q * n] = out[0][ip][q];
+                        if (sg.act[jj + 1]) o[(size_t)q * n + 1] = out[1][ip][q];
+                    }
+                }
+            }
+        }
+        wave_lds_fence();
+    }
+}
+
+// ---- q = box(a) . I + box(b) ----------------------------------------------------------------------------
+struct FinalRow {
+    double v[4][4];   // [plane][column]
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ AB /*[Z][4][H][W]*/,
+                                                    const uint8_t *__restrict__ guide, size_t step, size_t fs,
+                                                    const int *__restrict__ gnorm, int gnorm_stride, int NP,
+                                                    double *__restrict__ Q /*[Z][H][W]*/, int H, int W, int r, int TS, int rpc)
+{
+#pragma clang fp contract(fast)
+    __shared__ double2 s_d2[2 * 4 * 64];
+    StripGeom sg;
+    sg.init(blockIdx.x, TS, r, W);
+    const int l = sg.l, z = blockIdx.z, f = z / NP;
+    const size_t n = (size_t)H * W;
+    const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
+    const uint8_t *gf = guide + (size_t)f * fs;
+    const double *ab = AB + (size_t)z * 4 * n;
+
+    double acc[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
+
+    auto load_row = [&](int yy, FinalRow &R) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) R.v[k][0] = R.v[k][1] = R.v[k][2] = R.v[k][3] = 0.0;
+        if (yy < 0) return;
+        if (VEC) {
+            if (sg.in[0]) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double2 *pp = reinterpret_cast<const double2 *>(ab + (size_t)k * n + (size_t)yy * W + sg.x0);
+                    const double2 u = pp[0], v = pp[1];
+                    R.v[k][0] = u.x; R.v[k][1] = u.y; R.v[k][2] = v.x; R.v[k][3] = v.y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    R.v[k][j] = sg.in[j] ? ab[(size_t)k * n + (size_t)yy * W + sg.x0 + j] : 0.0;
+        }
+    };
+    auto accum = [&](const FinalRow &R, double sign) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[k][j] += sign * R.v[k][j];
+    };
+
+    const int y0 = blockIdx.y * rpc, y1 = min(H, y0 + rpc);
+    const double rdd = 1.0 / (double)(mx - mn);
+    int v = max(y0 - r, 0);
+    const int wend = min(y0 + r, H);
+    for (; v < wend; v += 2) {
+        FinalRow R0, R1;
+        load_row(v, R0);
+        load_row(v + 1 < wend ? v + 1 : -1, R1);
+        accum(R0, 1.0); accum(R1, 1.0);
+    }
+    FinalRow Ra, Rs;
+    load_row(y0 + r < H ? y0 + r : -1, Ra);
+    load_row(-1, Rs);
+    for (int y = y0; y < y1; ++y) {
+        accum(Ra, 1.0);
+        if (y > y0 && y - r - 1 >= 0) accum(Rs, -1.0);
+        load_row(y + 1 + r < H ? y + 1 + r : -1, Ra);
+        load_row((y + 1 > y0 && y - r >= 0) ? y - r : -1, Rs);
+        // the guide pixels of this row (needed only at the end; issued early)
+        uint32_t gw[3] = {0u, 0u, 0u};
+        if (VEC) {
+            if (sg.in[0]) {
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(gf + (size_t)y * step + (size_t)sg.x0 * 3);
+                gw[0] = q[0]; gw[1] = q[1]; gw[2] = q[2];
+            }
+        } else {
+            uint32_t b[12];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint8_t *q = gf + (size_t)y * step + (size_t)(sg.in[j] ? sg.x0 + j : 0) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) b[3 * j + c] = sg.in[j] ? (uint32_t)q[c] : 0u;
+            }
+#pragma unroll
+            for (int w = 0; w < 3; ++w) gw[w] = b[4 * w] | (b[4 * w + 1] << 8) | (b[4 * w + 2] << 16) | (b[4 * w + 3] << 24);
+        }
+        {
+            double D[4][4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double s0 = acc[k][0], s1 = s0 + acc[k][1], s2 = s1 + acc[k][2], s3 = s2 + acc[k][3];
+                const double e = wave_excl(s3);
+                D[k][0] = e + s0; D[k][1] = e + s1; D[k][2] = e + s2; D[k][3] = e + s3;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s_d2[(0 * 4 + j) * 64 + l] = make_double2(D[0][j], D[1][j]);
+                s_d2[(1 * 4 + j) * 64 + l] = make_double2(D[2][j], D[3][j]);
+            }
+        }
+        wave_lds_fence();
+        const double cy = count_of(y - r, y + r, H);
+        double qv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (sg.act[j]) {
+                const int x = sg.x0 + j;
+                const double rbase = 1.0 / (cy * count_of(x - r, x + r, W));
+                const double2 hA = s_d2[0 * 256 + sg.ah[j]], hB = s_d2[1 * 256 + sg.ah[j]];
+                double2 lA = s_d2[0 * 256 + sg.al[j]], lB = s_d2[1 * 256 + sg.al[j]];
+                if (!sg.lo_ok[j]) { lA = make_double2(0.0, 0.0); lB = lA; }
+                const double I0 = (double)(byte_of(gw, 3 * j) - mn) * rdd, I1 = (double)(byte_of(gw, 3 * j + 1) - mn) * rdd,
+                             I2 = (double)(byte_of(gw, 3 * j + 2) - mn) * rdd;
+                qv[j] = ((hA.x - lA.x) * I0 + (hA.y - lA.y) * I1 + (hB.x - lB.x) * I2 + (hB.y - lB.y)) * rbase;
+            }
+        }
+        double *o = Q + (size_t)z * n + (size_t)y * W + sg.x0;
+        if (VEC) {
+            if (sg.act[0]) {
+                reinterpret_cast<double2 *>(o)[0] = make_double2(qv[0], qv[1]);
+                reinterpret_cast<double2 *>(o)[1] = make_double2(qv[2], qv[3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (sg.act[j]) o[j] = qv[j];
+        }
+        wave_lds_fence();
+    }
+}
+
+}  // namespace
+
+// Launches the two kernels.  guide: 3-channel u8 frames; gnorm[f*gstride + {0,1}] = the frame's min / max guide
+// value; P [F][np][H][W] -> Q [F][np][H][W]; AB [F*np][4][H][W] scratch.
+int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs, const int *gnorm, int gstride,
+                       const double *P, double *Q, double *AB, int F, int np, int H, int W, int r, double eps)
+{
+    UWIP_REQUIRE(ctx, np == 1 || np == 2, "np must be 1 or 2");
+    UWIP_REQUIRE(ctx, r >= 1 && 2 * r <= 192, "radius out of range for the 256-column strip");
+    UWIP_REQUIRE(ctx, H <= 65535 && (size_t)F * np <= 65535, "too many rows/frames for one launch");
+    UWIP_REQUIRE(ctx, (uint64_t)256 * (2 * r + 1) * 65025ull < (1ull << 32), "window too large for the exact integer guide sums");
+    const int TS = 256 - 2 * r;
+    const unsigned strips = uwip_cdiv(W, TS);
+    // four adjacent columns of a lane are one aligned vector access when everything is a multiple of 4
+    const bool vec = (W % 4 == 0) && (r % 4 == 0) && (step % 4 == 0) && (fs % 4 == 0) && (((uintptr_t)guide) % 4 == 0) &&
+                     (((uintptr_t)P | (uintptr_t)Q | (uintptr_t)AB) % 16 == 0);
+    // row chunks: every chunk re-reads 2r halo rows, so use as few as keep the chip full (two resident waves
+    // per SIMD x 1024 SIMDs), preferring a whole number of "rounds"
+    auto chunks_for = [&](unsigned z, const void *kernel) {
+        const char *e = getenv("UWIP_GF_CHUNKS");
+        if (e && atoi(e) > 0) return std::max(1, std::min(atoi(e), std::max(1, H / (2 * r))));
+        int per_cu = 8;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+        int cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
+        const double slots = (double)per_cu * cus;
+        int best = 1;
+        double best_cost = 1e300;
+        for (int c = 1; c <= 16 && c <= std::max(1, H / (2 * r)); ++c) {
+            const double waves = (double)strips * z * c;
+            const double rounds = std::max(1.0, std::ceil(waves / slots));
+            const double rows = (double)(H + c - 1) / c + 2.0 * r;   // rows a wave walks
+            const double cost = rounds * rows;
+            if (cost < best_cost * 0.97) { best_cost = cost; best = c; }
+        }
+        return best;
+    };
+    {
+        const void *kern = np == 2 ? (vec ? (const void *)k_gf_ws_solve<2, true> : (const void *)k_gf_ws_solve<2, false>)
+                                   : (vec ? (const void *)k_gf_ws_solve<1, true> : (const void *)k_gf_ws_solve<1, false>);
+        const int c = chunks_for((unsigned)F, kern);
+        const int rpc = (H + c - 1) / c;
+        const dim3 grid(strips, uwip_cdiv(H, rpc), (unsigned)F);
+        uwip_kscope ks(ctx, "k_gf_ws_solve");
+        if (np == 2) {
+            if (vec) k_gf_ws_solve<2, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc);
+            else k_gf_ws_solve<2, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc);
+        } else {
+            if (vec) k_gf_ws_solve<1, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc);
+            else k_gf_ws_solve<1, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc);
+        }
+    }
+    {
+        const unsigned Z = (unsigned)F * np;
+        const int c = chunks_for(Z, vec ? (const void *)k_gf_ws_final<true> : (const void *)k_gf_ws_final<false>);
+        const int rpc = (H + c - 1) / c;
+        const dim3 grid(strips, uwip_cdiv(H, rpc), Z);
+        uwip_kscope ks(ctx, "k_gf_ws_final");
+        if (vec) k_gf_ws_final<true><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc);
+        else k_gf_ws_final<false><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc);
+    }
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}

@@ -58,6 +58,9 @@ void *uwip_host_ws(uwip_ctx *ctx, const char *name, size_t bytes);  // pinned ho
 const void *uwip_table_find(uwip_ctx *ctx, const std::string &key, size_t *bytes);
 const void *uwip_table_put(uwip_ctx *ctx, const std::string &key, const void *host, size_t bytes);
 int uwip_prof_flush(uwip_ctx *ctx);
+// guided_filter_ws.hip: the wave-strip guided filter (guide u8 x3, P [F][np][H][W] -> Q, AB [F*np][4][H][W] scratch)
+int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs, const int *gnorm, int gstride,
+                       const double *P, double *Q, double *AB, int F, int np, int H, int W, int r, double eps);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context, kernel)
 int uwip_lds_optin(uwip_ctx *ctx, const char *name, const void *func, size_t bytes);
 
