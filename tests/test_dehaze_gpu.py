@@ -63,7 +63,11 @@ def test_transmission_vs_golden_and_oracle(ctx):
     assert (t[:, :7] == 1).all() and (t[:, :, -7:] == 1).all()
 
 
-@pytest.mark.parametrize("shape,r,eps", [((90, 97), 40, 1e-3), ((85, 83), 20, 1e-2), ((200, 310), 40, 1e-3), ((81, 81), 40, 1e-3)])
+@pytest.mark.parametrize("shape,r,eps", [((90, 97), 40, 1e-3), ((85, 83), 20, 1e-2), ((200, 310), 40, 1e-3), ((81, 81), 40, 1e-3),
+                                         # odd radius over two strips; aligned (vector) path over several strips and row
+                                         # chunks; 2r > 192 takes the separable form
+                                         ((120, 260), 7, 1e-3), ((130, 400), 12, 1e-2), ((330, 512), 40, 1e-3),
+                                         ((210, 230), 100, 1e-3)])
 def test_guided_filter_vs_oracle(ctx, shape, r, eps):
     rng = np.random.default_rng(5)
     guide = synth.uw_frame(7, *shape)

@@ -101,8 +101,8 @@ template <int NP, bool VEC>
 __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ guide, size_t step, size_t fs,
                                                     const int *__restrict__ gnorm, int gnorm_stride,
                                                     const double *__restrict__ P /*[F][NP][H][W]*/,
-                                                    double *__restrict__ AB /*[F*NP][4][H][W]*/, int H, int W, int r, double eps,
-                                                    int TS, int rpc)
+                                                    double *__restrict__ AB /*[F*NP][4][H][W]: column prefix sums of a, b*/,
+                                                    int H, int W, int r, double eps, int TS, int rpc, int fdiv)
 {
 #pragma clang fp contract(fast)
     __shared__ uint4 s_u4[2 * 4 * 64];
@@ -110,21 +110,26 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
     __shared__ double2 s_d2[NP * 2 * 4 * 64];
     StripGeom sg;
     sg.init(blockIdx.x, TS, r, W);
-    const int l = sg.l, f = blockIdx.z;
+    // blockIdx.z counts groups of NP p-planes; fdiv of them share a frame (fdiv = np / NP)
+    const int l = sg.l, zg = blockIdx.z, f = zg / fdiv;
     const size_t n = (size_t)H * W;
     const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
     const uint32_t fillw = (uint32_t)mn * 0x01010101u;
     const uint8_t *gf = guide + (size_t)f * fs;
-    const double *pin = P + (size_t)f * NP * n;
+    const double *pin = P + (size_t)zg * NP * n;
 
     uint32_t gi[4][9];
     double pf[4][NP][4];
+    double cs[4][NP][4];   // running column sums of a0, a1, a2, b over this block's rows
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) gi[j][k] = 0u;
 #pragma unroll
-        for (int ip = 0; ip < NP; ++ip) pf[j][ip][0] = pf[j][ip][1] = pf[j][ip][2] = pf[j][ip][3] = 0.0;
+        for (int ip = 0; ip < NP; ++ip) {
+            pf[j][ip][0] = pf[j][ip][1] = pf[j][ip][2] = pf[j][ip][3] = 0.0;
+            cs[j][ip][0] = cs[j][ip][1] = cs[j][ip][2] = cs[j][ip][3] = 0.0;
+        }
     }
 
     auto load_row = [&](int yy, SolveRow<NP> &R) {
@@ -275,15 +280,17 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
                         const double a0 = (c0 * k00 + c1 * k01 + c2 * k02) * rdet;
                         const double a1 = (c0 * k01 + c1 * k11 + c2 * k12) * rdet;
                         const double a2 = (c0 * k02 + c1 * k12 + c2 * k22) * rdet;
-                        out[j2][ip][0] = a0; out[j2][ip][1] = a1; out[j2][ip][2] = a2;
-                        out[j2][ip][3] = mp - a0 * m0 - a1 * m1 - a2 * m2;
+                        cs[j][ip][0] += a0; cs[j][ip][1] += a1; cs[j][ip][2] += a2;
+                        cs[j][ip][3] += mp - a0 * m0 - a1 * m1 - a2 * m2;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) out[j2][ip][q] = cs[j][ip][q];
                     }
                 }
             }
             const size_t i = (size_t)y * W + sg.x0 + jj;
 #pragma unroll
             for (int ip = 0; ip < NP; ++ip) {
-                double *o = AB + ((size_t)f * NP + ip) * 4 * n + i;
+                double *o = AB + ((size_t)zg * NP + ip) * 4 * n + i;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (VEC) {
@@ -300,15 +307,22 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
 }
 
 // ---- q = box(a) . I + box(b) ----------------------------------------------------------------------------
+// k_gf_ws_solve leaves S = the running column sums of a, b (restarting at each of its row chunks), so the vertical
+// box sum of row y is  S[y + r] - S[y - r - 1]  (plus the previous chunk's last row when the two straddle a chunk
+// start): no sliding window, no warm-up rows.  A wave walks "chains" of rows 2r+1 apart,
+//     y = s, s + (2r+1), s + 2(2r+1), ...
+// because S[y + r] of one link is S[y' - r - 1] of the next: every row of S is read once per chain set instead of
+// twice.  Chains are independent, so any number of waves can share a strip at no extra traffic.
 struct FinalRow {
     double v[4][4];   // [plane][column]
 };
 
 template <bool VEC>
-__global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ AB /*[Z][4][H][W]*/,
+__global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S /*[Z][4][H][W]*/,
                                                     const uint8_t *__restrict__ guide, size_t step, size_t fs,
                                                     const int *__restrict__ gnorm, int gnorm_stride, int NP,
-                                                    double *__restrict__ Q /*[Z][H][W]*/, int H, int W, int r, int TS, int rpc)
+                                                    double *__restrict__ Q /*[Z][H][W]*/, int H, int W, int r, int TS,
+                                                    int rpc /*rows per chunk of S*/, int spw /*chains per wave*/)
 {
 #pragma clang fp contract(fast)
     __shared__ double2 s_d2[2 * 4 * 64];
@@ -318,11 +332,11 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ A
     const size_t n = (size_t)H * W;
     const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
     const uint8_t *gf = guide + (size_t)f * fs;
-    const double *ab = AB + (size_t)z * 4 * n;
-
-    double acc[4][4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
+    const double *sp = S + (size_t)z * 4 * n;
+    const int D = 2 * r + 1;
+    const int s_end = min(min(D, H), (int)(blockIdx.y + 1) * spw);
+    int s = blockIdx.y * spw, y = s;
+    if (s >= s_end) return;
 
     auto load_row = [&](int yy, FinalRow &R) {
 #pragma unroll
@@ -332,7 +346,7 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ A
             if (sg.in[0]) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const double2 *pp = reinterpret_cast<const double2 *>(ab + (size_t)k * n + (size_t)yy * W + sg.x0);
+                    const double2 *pp = reinterpret_cast<const double2 *>(sp + (size_t)k * n + (size_t)yy * W + sg.x0);
                     const double2 u = pp[0], v = pp[1];
                     R.v[k][0] = u.x; R.v[k][1] = u.y; R.v[k][2] = v.x; R.v[k][3] = v.y;
                 }
@@ -342,35 +356,37 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ A
             for (int k = 0; k < 4; ++k)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    R.v[k][j] = sg.in[j] ? ab[(size_t)k * n + (size_t)yy * W + sg.x0 + j] : 0.0;
+                    R.v[k][j] = sg.in[j] ? sp[(size_t)k * n + (size_t)yy * W + sg.x0 + j] : 0.0;
         }
     };
-    auto accum = [&](const FinalRow &R, double sign) {
+    const double rdd = 1.0 / (double)(mx - mn);
+
+    // one link of a chain: `cur` holds S[min(y + r, H - 1)], `prev` holds S[y - r - 1] (zeros above the image).
+    // Leaves the next link's rows in (prev := next cur, cur := next prev) -- the caller swaps the two buffers.
+    auto link = [&](FinalRow &prev, FinalRow &cur) -> bool {
+        const int hi = min(y + r, H - 1), lo = y - r - 1;
+        double d[4][4];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[k][j] += sign * R.v[k][j];
-    };
-
-    const int y0 = blockIdx.y * rpc, y1 = min(H, y0 + rpc);
-    const double rdd = 1.0 / (double)(mx - mn);
-    int v = max(y0 - r, 0);
-    const int wend = min(y0 + r, H);
-    for (; v < wend; v += 2) {
-        FinalRow R0, R1;
-        load_row(v, R0);
-        load_row(v + 1 < wend ? v + 1 : -1, R1);
-        accum(R0, 1.0); accum(R1, 1.0);
-    }
-    FinalRow Ra, Rs;
-    load_row(y0 + r < H ? y0 + r : -1, Ra);
-    load_row(-1, Rs);
-    for (int y = y0; y < y1; ++y) {
-        accum(Ra, 1.0);
-        if (y > y0 && y - r - 1 >= 0) accum(Rs, -1.0);
-        load_row(y + 1 + r < H ? y + 1 + r : -1, Ra);
-        load_row((y + 1 > y0 && y - r >= 0) ? y - r : -1, Rs);
-        // the guide pixels of this row (needed only at the end; issued early)
+            for (int j = 0; j < 4; ++j) d[k][j] = cur.v[k][j] - prev.v[k][j];
+        if (lo >= 0 && hi / rpc != lo / rpc) {   // uniform: the window straddles a chunk start of S
+            FinalRow E;
+            load_row((hi / rpc) * rpc - 1, E);
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[k][j] += E.v[k][j];
+        }
+        // next link (prefetched under the horizontal pass of this one)
+        int yn = y + D, sn = s;
+        bool chain_start = false;
+        if (yn >= H) { sn = s + 1; yn = sn; chain_start = true; }
+        const bool more = sn < s_end;
+        if (more) {
+            load_row(min(yn + r, H - 1), prev);                    // next cur
+            if (chain_start) load_row(yn - r - 1, cur);            // next prev (else: this cur)
+        }
         uint32_t gw[3] = {0u, 0u, 0u};
         if (VEC) {
             if (sg.in[0]) {
@@ -388,19 +404,16 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ A
 #pragma unroll
             for (int w = 0; w < 3; ++w) gw[w] = b[4 * w] | (b[4 * w + 1] << 8) | (b[4 * w + 2] << 16) | (b[4 * w + 3] << 24);
         }
-        {
-            double D[4][4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const double s0 = acc[k][0], s1 = s0 + acc[k][1], s2 = s1 + acc[k][2], s3 = s2 + acc[k][3];
-                const double e = wave_excl(s3);
-                D[k][0] = e + s0; D[k][1] = e + s1; D[k][2] = e + s2; D[k][3] = e + s3;
-            }
+        for (int k = 0; k < 4; ++k) {
+            const double s1 = d[k][0] + d[k][1], s2 = s1 + d[k][2], s3 = s2 + d[k][3];
+            const double e = wave_excl(s3);
+            d[k][0] += e; d[k][1] = e + s1; d[k][2] = e + s2; d[k][3] = e + s3;
+        }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                s_d2[(0 * 4 + j) * 64 + l] = make_double2(D[0][j], D[1][j]);
-                s_d2[(1 * 4 + j) * 64 + l] = make_double2(D[2][j], D[3][j]);
-            }
+        for (int j = 0; j < 4; ++j) {
+            s_d2[(0 * 4 + j) * 64 + l] = make_double2(d[0][j], d[1][j]);
+            s_d2[(1 * 4 + j) * 64 + l] = make_double2(d[2][j], d[3][j]);
         }
         wave_lds_fence();
         const double cy = count_of(y - r, y + r, H);
@@ -430,69 +443,95 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ A
                 if (sg.act[j]) o[j] = qv[j];
         }
         wave_lds_fence();
+        y = yn; s = sn;
+        return more;
+    };
+
+    FinalRow A, B;
+    load_row(y - r - 1, A);
+    load_row(min(y + r, H - 1), B);
+    for (;;) {
+        if (!link(A, B)) break;
+        if (!link(B, A)) break;
     }
 }
 
 }  // namespace
 
 // Launches the two kernels.  guide: 3-channel u8 frames; gnorm[f*gstride + {0,1}] = the frame's min / max guide
-// value; P [F][np][H][W] -> Q [F][np][H][W]; AB [F*np][4][H][W] scratch.
+// value; P [F][np][H][W] -> Q [F][np][H][W]; AB [F*np][4][H][W] scratch (column prefix sums of a, b).
 int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs, const int *gnorm, int gstride,
                        const double *P, double *Q, double *AB, int F, int np, int H, int W, int r, double eps)
 {
     UWIP_REQUIRE(ctx, np == 1 || np == 2, "np must be 1 or 2");
     UWIP_REQUIRE(ctx, r >= 1 && 2 * r <= 192, "radius out of range for the 256-column strip");
+    UWIP_REQUIRE(ctx, H >= 2 * r + 1 && W >= 2 * r + 1, "guided filter needs rows, cols >= 2r+1");
     UWIP_REQUIRE(ctx, H <= 65535 && (size_t)F * np <= 65535, "too many rows/frames for one launch");
     UWIP_REQUIRE(ctx, (uint64_t)256 * (2 * r + 1) * 65025ull < (1ull << 32), "window too large for the exact integer guide sums");
-    const int TS = 256 - 2 * r;
+    const int TS = 256 - 2 * r, D = 2 * r + 1;
     const unsigned strips = uwip_cdiv(W, TS);
     // four adjacent columns of a lane are one aligned vector access when everything is a multiple of 4
     const bool vec = (W % 4 == 0) && (r % 4 == 0) && (step % 4 == 0) && (fs % 4 == 0) && (((uintptr_t)guide) % 4 == 0) &&
                      (((uintptr_t)P | (uintptr_t)Q | (uintptr_t)AB) % 16 == 0);
-    // row chunks: every chunk re-reads 2r halo rows, so use as few as keep the chip full (two resident waves
-    // per SIMD x 1024 SIMDs), preferring a whole number of "rounds"
-    auto chunks_for = [&](unsigned z, const void *kernel) {
-        const char *e = getenv("UWIP_GF_CHUNKS");
-        if (e && atoi(e) > 0) return std::max(1, std::min(atoi(e), std::max(1, H / (2 * r))));
+    int cus = 256;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
+    auto slots_of = [&](const void *kernel) {
         int per_cu = 8;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
-        int cus = 256;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
-        const double slots = (double)per_cu * cus;
-        int best = 1;
-        double best_cost = 1e300;
-        for (int c = 1; c <= 16 && c <= std::max(1, H / (2 * r)); ++c) {
-            const double waves = (double)strips * z * c;
-            const double rounds = std::max(1.0, std::ceil(waves / slots));
-            const double rows = (double)(H + c - 1) / c + 2.0 * r;   // rows a wave walks
-            const double cost = rounds * rows;
-            if (cost < best_cost * 0.97) { best_cost = cost; best = c; }
-        }
-        return best;
+        return (double)per_cu * cus;
     };
+    const char *env_split = getenv("UWIP_GF_SPLIT");
+    const bool split = np == 2 && env_split && atoi(env_split) > 0;   // two one-plane solves instead of a fused one
+    const int knp = split ? 1 : np;
+    const unsigned zs = (unsigned)F * (np / knp);
+    const void *ksolve = knp == 2 ? (vec ? (const void *)k_gf_ws_solve<2, true> : (const void *)k_gf_ws_solve<2, false>)
+                                  : (vec ? (const void *)k_gf_ws_solve<1, true> : (const void *)k_gf_ws_solve<1, false>);
+    // solve: every row chunk re-reads 2r warm-up rows, so use as few chunks as keep the chip full, preferring a whole
+    // number of "rounds" of resident waves.  A chunk is at least 2r+1 rows (k_gf_ws_final relies on it).
+    int c = 1;
     {
-        const void *kern = np == 2 ? (vec ? (const void *)k_gf_ws_solve<2, true> : (const void *)k_gf_ws_solve<2, false>)
-                                   : (vec ? (const void *)k_gf_ws_solve<1, true> : (const void *)k_gf_ws_solve<1, false>);
-        const int c = chunks_for((unsigned)F, kern);
-        const int rpc = (H + c - 1) / c;
-        const dim3 grid(strips, uwip_cdiv(H, rpc), (unsigned)F);
+        const int cmax = std::max(1, H / D);
+        const char *e = getenv("UWIP_GF_CHUNKS");
+        if (e && atoi(e) > 0) c = std::min(atoi(e), cmax);
+        else {
+            const double slots = slots_of(ksolve);
+            double best_cost = 1e300;
+            for (int t = 1; t <= 16 && t <= cmax; ++t) {
+                const double waves = (double)strips * zs * t;
+                const double rounds = std::max(1.0, std::ceil(waves / slots));
+                const double cost = rounds * ((double)((H + t - 1) / t) + 2.0 * r);
+                if (cost < best_cost * 0.97) { best_cost = cost; c = t; }
+            }
+        }
+    }
+    int rpc = (H + c - 1) / c;
+    if (rpc < D) rpc = D;
+    {
+        const dim3 grid(strips, uwip_cdiv(H, rpc), zs);
         uwip_kscope ks(ctx, "k_gf_ws_solve");
-        if (np == 2) {
-            if (vec) k_gf_ws_solve<2, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc);
-            else k_gf_ws_solve<2, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc);
+        const int fdiv = np / knp;
+        if (knp == 2) {
+            if (vec) k_gf_ws_solve<2, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv);
+            else k_gf_ws_solve<2, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv);
         } else {
-            if (vec) k_gf_ws_solve<1, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc);
-            else k_gf_ws_solve<1, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc);
+            if (vec) k_gf_ws_solve<1, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv);
+            else k_gf_ws_solve<1, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv);
         }
     }
     {
+        // final: chains are independent, so split the 2r+1 chain starts over enough waves for ~4 rounds
         const unsigned Z = (unsigned)F * np;
-        const int c = chunks_for(Z, vec ? (const void *)k_gf_ws_final<true> : (const void *)k_gf_ws_final<false>);
-        const int rpc = (H + c - 1) / c;
-        const dim3 grid(strips, uwip_cdiv(H, rpc), Z);
+        const void *kfinal = vec ? (const void *)k_gf_ws_final<true> : (const void *)k_gf_ws_final<false>;
+        const int nchain = std::min(D, H);
+        int groups = (int)std::ceil(4.0 * slots_of(kfinal) / ((double)strips * Z));
+        const char *e = getenv("UWIP_GF_GROUPS");
+        if (e && atoi(e) > 0) groups = atoi(e);
+        groups = std::max(1, std::min(groups, nchain));
+        const int spw = (nchain + groups - 1) / groups;
+        const dim3 grid(strips, uwip_cdiv(nchain, spw), Z);
         uwip_kscope ks(ctx, "k_gf_ws_final");
-        if (vec) k_gf_ws_final<true><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc);
-        else k_gf_ws_final<false><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc);
+        if (vec) k_gf_ws_final<true><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw);
+        else k_gf_ws_final<false><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw);
     }
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
