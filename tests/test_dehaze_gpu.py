@@ -65,9 +65,9 @@ def test_transmission_vs_golden_and_oracle(ctx):
 
 @pytest.mark.parametrize("shape,r,eps", [((90, 97), 40, 1e-3), ((85, 83), 20, 1e-2), ((200, 310), 40, 1e-3), ((81, 81), 40, 1e-3),
                                          # odd radius over two strips; aligned (vector) path over several strips and row
-                                         # chunks; 2r > 192 takes the separable form
+                                         # chunks; the largest supported radius
                                          ((120, 260), 7, 1e-3), ((130, 400), 12, 1e-2), ((330, 512), 40, 1e-3),
-                                         ((210, 230), 100, 1e-3)])
+                                         ((200, 260), 96, 1e-3)])
 def test_guided_filter_vs_oracle(ctx, shape, r, eps):
     rng = np.random.default_rng(5)
     guide = synth.uw_frame(7, *shape)
@@ -75,6 +75,13 @@ def test_guided_filter_vs_oracle(ctx, shape, r, eps):
     q = bg.guided_filter(ctx, _dev(guide), _dev(p), r, eps).cpu().numpy()[0]
     qo = dz.guided_filter(dz.normalize_input(guide), p, r, eps)
     assert np.abs(q - qo).max() <= TOL
+
+
+def test_guided_filter_rejects_large_radius(ctx):
+    import uwimageproc_amd as uw
+    guide = synth.uw_frame(7, 210, 230)
+    with pytest.raises(uw.UwipError):
+        bg.guided_filter(ctx, _dev(guide), _dev(np.zeros((210, 230))), 100, 1e-3)
 
 
 def test_guided_filter_rejects_small_images(ctx):

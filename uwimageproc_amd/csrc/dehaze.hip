@@ -11,10 +11,10 @@
 // monotone map: they run on the uint8 planes and the float64 value is looked up
 // afterwards (exact, not an approximation).
 //
-// Box filters (radius 40) are separable: a vertical sliding-window sum with
-// float64 accumulators (one thread per column and row chunk) followed by a
-// horizontal pass that prefix-scans a row in LDS; every mean divides by the
-// analytic in-image window size, as guidedfilter.py:67 does.
+// The guided filter (radius 40 box filters) is in guided_filter_ws.hip: two
+// streaming kernels, vertical sums in registers, horizontal sums by a wave
+// prefix scan; every mean divides by the analytic in-image window size, as
+// guidedfilter.py:67 does.
 #include "uwip_internal.hpp"
 #include "device_utils.hpp"
 #include <algorithm>
@@ -274,445 +274,6 @@ __global__ __launch_bounds__(256) void k_transmission(const uint8_t *__restrict_
         if (traw) { traw[(size_t)f * 2 * n + i] = t0; traw[(size_t)f * 2 * n + n + i] = t1; }
         P[(size_t)f * 2 * n + i] = fmax(t0, tmin);
         P[(size_t)f * 2 * n + n + i] = fmax(t1, tmin);
-    }
-}
-
-// ---- vertical sliding-window sums ------------------------------------------------
-// MODE 1: per-p statistics: 4 planes (p, I0 p, I1 p, I2 p); blockIdx.z = f*np + ip
-// MODE 2: plain planes: blockIdx.z = plane
-// (the nine guide statistics are exact integers: k_vsum_guide_u32 below)
-template <int MODE>
-__global__ __launch_bounds__(256) void k_vsum(const uint8_t *__restrict__ guide, size_t step, size_t fs,
-                                              const int *__restrict__ gnorm /*[F][2]*/, int gnorm_stride,
-                                              const double *__restrict__ in, double *__restrict__ out,
-                                              int H, int W, int r, int rows_per_chunk, int np)
-{
-    static_assert(MODE == 1 || MODE == 2, "guide statistics use k_vsum_guide_u32");
-    constexpr int NS = MODE == 1 ? 4 : 1;
-    __shared__ double s_T[256];
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int z = blockIdx.z;
-    const int f = MODE == 1 ? z / np : z;
-    const size_t n = (size_t)H * W;
-    if (MODE != 2) {
-        const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
-        s_T[threadIdx.x] = (int)threadIdx.x >= mn ? normv(threadIdx.x, mn, mx) : 0.0;
-        __syncthreads();
-    }
-    if (x >= W) return;
-    const uint8_t *g = MODE != 2 ? guide + (size_t)f * fs + (size_t)x * 3 : nullptr;
-    const double *pin = in + (size_t)z * n + x;
-    double *po = out + (size_t)z * NS * n + x;
-    const int y0 = blockIdx.y * rows_per_chunk, y1 = min(H, y0 + rows_per_chunk);
-    double s[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) s[k] = 0.0;
-    auto accum = [&](int yy, double sign) {
-        if (MODE == 1) {
-            const uint8_t *p = g + (size_t)yy * step;
-            const double a = s_T[p[0]], b = s_T[p[1]], c = s_T[p[2]];
-            const double pv = pin[(size_t)yy * W];
-            s[0] += sign * pv; s[1] += sign * (a * pv); s[2] += sign * (b * pv); s[3] += sign * (c * pv);
-        } else {
-            s[0] += sign * pin[(size_t)yy * W];
-        }
-    };
-    for (int yy = max(0, y0 - r); yy <= min(H - 1, y0 + r); ++yy) accum(yy, 1.0);
-    for (int y = y0; y < y1; ++y) {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) po[(size_t)k * n + (size_t)y * W] = s[k];
-        if (y + r + 1 < H) accum(y + r + 1, 1.0);
-        if (y - r >= 0) accum(y - r, -1.0);
-    }
-}
-
-// Guide statistics as exact integers: with u = v - min (0..255), sums of u_i and u_i*u_j over an 81-row window
-// fit 32 bits (81 * 255^2 = 5.3e6) and stay exact, so the nine guide planes are uint32 instead of float64.
-__global__ __launch_bounds__(256) void k_vsum_guide_u32(const uint8_t *__restrict__ guide, size_t step, size_t fs,
-                                                        const int *__restrict__ gnorm, int gnorm_stride,
-                                                        uint32_t *__restrict__ out /*[F][9][H][W]*/, int H, int W, int r,
-                                                        int rows_per_chunk)
-{
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int f = blockIdx.z;
-    if (x >= W) return;
-    const size_t n = (size_t)H * W;
-    const int mn = gnorm[(size_t)f * gnorm_stride];
-    const uint8_t *g = guide + (size_t)f * fs + (size_t)x * 3;
-    uint32_t *po = out + (size_t)f * 9 * n + x;
-    const int y0 = blockIdx.y * rows_per_chunk, y1 = min(H, y0 + rows_per_chunk);
-    uint32_t s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    auto accum = [&](int yy, bool add) {
-        const uint8_t *p = g + (size_t)yy * step;
-        const uint32_t a = (uint32_t)max((int)p[0] - mn, 0), b = (uint32_t)max((int)p[1] - mn, 0), c = (uint32_t)max((int)p[2] - mn, 0);
-        const uint32_t v[9] = {a, b, c, a * a, a * b, a * c, b * b, b * c, c * c};
-#pragma unroll
-        for (int k = 0; k < 9; ++k) s[k] = add ? s[k] + v[k] : s[k] - v[k];
-    };
-    for (int yy = max(0, y0 - r); yy <= min(H - 1, y0 + r); ++yy) accum(yy, true);
-    for (int y = y0; y < y1; ++y) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) po[(size_t)k * n + (size_t)y * W] = s[k];
-        if (y + r + 1 < H) accum(y + r + 1, true);
-        if (y - r >= 0) accum(y - r, false);
-    }
-}
-
-__device__ __forceinline__ double box_base(int y, int x, int H, int W, int r)
-{
-    const int cy = min(y + r, H - 1) - max(y - r, 0) + 1;
-    const int cx = min(x + r, W - 1) - max(x - r, 0) + 1;
-    return (double)cy * (double)cx;
-}
-
-// ---- horizontal box sums fused into their consumers ------------------------------------
-// A block owns HSEG output pixels of one row.  For each of NPL vertical-sum planes it loads the row
-// segment with an r+1 / r halo into LDS, prefix-scans it (one wave per plane, 64 elements per step)
-// and every pixel's horizontal window sum is then a difference of two LDS values.  This replaces a
-// separate read+write pass per plane (the former k_hsum).
-constexpr int HSEG = 256;
-
-// Stage NPL row segments into LDS and turn each into its inclusive prefix scan.
-// s: [NPL][LW] doubles, LW = HSEG + 2r + 1; element j <-> image column x0 - r - 1 + j.
-//  1. every thread issues ALL its global loads (2 per plane) before the first LDS store, so a block pays
-//     one memory latency, not one per plane;
-//  2. TPP = 256 / NPL threads own one plane each: a thread reads its contiguous run into registers,
-//     scans it there, publishes the run total, and after one barrier writes run + offset back.
-constexpr int RUNMAX = 24;
-// In-place inclusive prefix scan of NI uint32 rows and NF float64 rows of LW entries already in LDS.
-// TPP = 256 / (NI + NF) threads own one row each; a thread scans its contiguous run in registers, publishes the
-// run total and, after ONE barrier common to all lanes, writes run + offset back.  Ends with a barrier.
-template <int NI, int NF>
-__device__ __forceinline__ void scan_planes(uint32_t *si, double *sf, double *s_tot, int LW)
-{
-    constexpr int NPL = NI + NF;
-    constexpr int TPP = 256 / NPL;
-    const int k = threadIdx.x / TPP, t = threadIdx.x - k * TPP;
-    const int run = (LW + TPP - 1) / TPP;
-    const int a = t * run, e = min(a + run, LW);
-    uint32_t *s_toti = reinterpret_cast<uint32_t *>(s_tot);
-    const bool is_i = k < NI, is_f = !is_i && k < NPL;
-    uint32_t *irow = si + (size_t)(is_i ? k : 0) * LW;
-    double *frow = sf + (size_t)(is_f ? k - NI : 0) * LW;
-    uint32_t vi[RUNMAX], acci = 0;
-    double vf[RUNMAX], accf = 0.0;
-    if (is_i) {
-#pragma unroll
-        for (int i = 0; i < RUNMAX; ++i) vi[i] = (a + i < e) ? irow[a + i] : 0u;
-#pragma unroll
-        for (int i = 0; i < RUNMAX; ++i) { acci += vi[i]; vi[i] = acci; }
-        s_toti[(k * 64 + t) * 2] = acci;
-    } else if (is_f) {
-#pragma unroll
-        for (int i = 0; i < RUNMAX; ++i) vf[i] = (a + i < e) ? frow[a + i] : 0.0;
-#pragma unroll
-        for (int i = 0; i < RUNMAX; ++i) { accf += vf[i]; vf[i] = accf; }
-        s_tot[k * 64 + t] = accf;
-    }
-    __syncthreads();               // one barrier for every lane, whatever its plane type
-    if (is_i) {
-        uint32_t off = 0;
-        for (int i = 0; i < t; ++i) off += s_toti[(k * 64 + i) * 2];
-#pragma unroll
-        for (int i = 0; i < RUNMAX; ++i) if (a + i < e) irow[a + i] = vi[i] + off;
-    } else if (is_f) {
-        double off = 0.0;
-        for (int i = 0; i < t; ++i) off += s_tot[k * 64 + i];
-#pragma unroll
-        for (int i = 0; i < RUNMAX; ++i) if (a + i < e) frow[a + i] = vf[i] + off;
-    }
-    __syncthreads();
-}
-
-template <int NI, int NF>
-__device__ __forceinline__ void load_scan(uint32_t *si /*[NI][LW]*/, double *sf /*[NF][LW]*/, double *s_tot /*[(NI+NF)][64]*/,
-                                          int LW, const uint32_t *const *iplanes, const double *const (&fplanes)[NF],
-                                          size_t row_off, int x0, int r, int W)
-{
-    {
-        uint32_t vi[NI > 0 ? NI : 1][2];
-        double vf[NF][2];
-        const int j0 = threadIdx.x, j1 = threadIdx.x + 256;
-        const int xa = x0 - r - 1 + j0, xb = x0 - r - 1 + j1;
-        const bool oka = xa >= 0 && xa < W, okb = j1 < LW && xb >= 0 && xb < W;
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            vi[k][0] = oka ? iplanes[k][row_off + xa] : 0u;
-            vi[k][1] = okb ? iplanes[k][row_off + xb] : 0u;
-        }
-#pragma unroll
-        for (int k = 0; k < NF; ++k) {
-            vf[k][0] = oka ? fplanes[k][row_off + xa] : 0.0;
-            vf[k][1] = okb ? fplanes[k][row_off + xb] : 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < NI; ++k) {
-            si[(size_t)k * LW + j0] = vi[k][0];
-            if (j1 < LW) si[(size_t)k * LW + j1] = vi[k][1];
-        }
-#pragma unroll
-        for (int k = 0; k < NF; ++k) {
-            sf[(size_t)k * LW + j0] = vf[k][0];
-            if (j1 < LW) sf[(size_t)k * LW + j1] = vf[k][1];
-        }
-    }
-    __syncthreads();
-    scan_planes<NI, NF>(si, sf, s_tot, LW);
-}
-
-// window sum over columns [max(x-r,0), min(x+r,W-1)] from the scanned row
-__device__ __forceinline__ double win(const double *row, int x, int x0, int r, int W)
-{
-    const int o = x0 - r - 1;
-    return row[min(x + r, W - 1) - o] - row[max(x - r, 0) - 1 - o];
-}
-
-__device__ __forceinline__ uint32_t win_u32(const uint32_t *row, int x, int x0, int r, int W)
-{
-    const int o = x0 - r - 1;
-    return row[min(x + r, W - 1) - o] - row[max(x - r, 0) - 1 - o];       // exact (mod 2^32, true value < 2^32)
-}
-
-// ---- guided filter eq.14-15 with the horizontal sums fused: a = cov inv(Sigma + eps I), b = mean_p - a.mean
-template <int NP>
-__global__ __launch_bounds__(256) void k_gf_solve_h(const uint32_t *__restrict__ VG /*[F][9] vertical integer sums*/,
-                                                    const double *__restrict__ VP /*[F*NP][4] vertical sums*/,
-                                                    double *__restrict__ AB /*[F*NP][4]*/, int H, int W, int r, double eps,
-                                                    const int *__restrict__ gnorm, int gnorm_stride)
-{
-    extern __shared__ __attribute__((aligned(16))) double s_rows[];
-    constexpr int NF = 4 * NP;
-    const int LW = HSEG + 2 * r + 1;
-    double *sf = s_rows;                                                   // [NF][LW] float64
-    uint32_t *si = reinterpret_cast<uint32_t *>(s_rows + (size_t)NF * LW); // [9][LW] uint32
-    __shared__ double s_tot[(9 + NF) * 64];
-    const int x0 = blockIdx.x * HSEG, y = blockIdx.y, f = blockIdx.z;
-    const size_t n = (size_t)H * W;
-    const uint32_t *iplanes[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) iplanes[k] = VG + ((size_t)f * 9 + k) * n;
-    const double *fplanes[NF];
-#pragma unroll
-    for (int k = 0; k < NF; ++k) fplanes[k] = VP + ((size_t)f * NF + k) * n;
-    load_scan<9, NF>(si, sf, s_tot, LW, iplanes, fplanes, (size_t)y * W, x0, r, W);
-    const int x = x0 + threadIdx.x;
-    if (x >= W) return;
-    // reciprocals instead of ~30 float64 divisions per pixel (differs from true division by <= 1 ulp)
-    const double rbase = 1.0 / box_base(y, x, H, W, r);
-    const double rdd = 1.0 / (double)(gnorm[(size_t)f * gnorm_stride + 1] - gnorm[(size_t)f * gnorm_stride]);
-    const double r1 = rdd * rbase, r2 = (rdd * rdd) * rbase;
-    double g[9];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) g[k] = (double)win_u32(si + (size_t)k * LW, x, x0, r, W) * r1;
-#pragma unroll
-    for (int k = 3; k < 9; ++k) g[k] = (double)win_u32(si + (size_t)k * LW, x, x0, r, W) * r2;
-    const double m0 = g[0], m1 = g[1], m2 = g[2];
-    const double s00 = g[3] - m0 * m0 + eps, s01 = g[4] - m0 * m1, s02 = g[5] - m0 * m2;
-    const double s11 = g[6] - m1 * m1 + eps, s12 = g[7] - m1 * m2, s22 = g[8] - m2 * m2 + eps;
-    // symmetric 3x3 inverse by cofactors
-    const double k00 = s11 * s22 - s12 * s12, k01 = s02 * s12 - s01 * s22, k02 = s01 * s12 - s02 * s11;
-    const double k11 = s00 * s22 - s02 * s02, k12 = s01 * s02 - s00 * s12, k22 = s00 * s11 - s01 * s01;
-    const double rdet = 1.0 / (s00 * k00 + s01 * k01 + s02 * k02);
-    const size_t i = (size_t)y * W + x;
-#pragma unroll
-    for (int ip = 0; ip < NP; ++ip) {
-        const double *pr = sf + (size_t)(4 * ip) * LW;
-        const double mp = win(pr, x, x0, r, W) * rbase;
-        const double c0 = win(pr + LW, x, x0, r, W) * rbase - m0 * mp;
-        const double c1 = win(pr + 2 * (size_t)LW, x, x0, r, W) * rbase - m1 * mp;
-        const double c2 = win(pr + 3 * (size_t)LW, x, x0, r, W) * rbase - m2 * mp;
-        const double a0 = (c0 * k00 + c1 * k01 + c2 * k02) * rdet;
-        const double a1 = (c0 * k01 + c1 * k11 + c2 * k12) * rdet;
-        const double a2 = (c0 * k02 + c1 * k12 + c2 * k22) * rdet;
-        double *o = AB + ((size_t)f * NP + ip) * 4 * n;
-        o[i] = a0; o[n + i] = a1; o[2 * n + i] = a2;
-        o[3 * n + i] = mp - a0 * m0 - a1 * m1 - a2 * m2;
-    }
-}
-
-// ---- guided filter eq.16 with the horizontal sums fused: q = (box(a).I + box(b)) / base ----
-template <int NP>
-__global__ __launch_bounds__(256) void k_gf_final_h(const double *__restrict__ VAB /*[F*NP][4] vertical sums of a,b*/,
-                                                    const uint8_t *__restrict__ guide, size_t step, size_t fs,
-                                                    const int *__restrict__ gnorm, int gnorm_stride,
-                                                    double *__restrict__ Q /*[F*NP]*/, int H, int W, int r)
-{
-    extern __shared__ __attribute__((aligned(16))) double s_rows[];
-    constexpr int NPL = 4 * NP;
-    const int LW = HSEG + 2 * r + 1;
-    const int x0 = blockIdx.x * HSEG, y = blockIdx.y, f = blockIdx.z;
-    const size_t n = (size_t)H * W;
-    const double *planes[NPL];
-#pragma unroll
-    for (int k = 0; k < NPL; ++k) planes[k] = VAB + ((size_t)f * NPL + k) * n;
-    __shared__ double s_tot[NPL * 64];
-    load_scan<0, NPL>(nullptr, s_rows, s_tot, LW, nullptr, planes, (size_t)y * W, x0, r, W);
-    const int x = x0 + threadIdx.x;
-    if (x >= W) return;
-    const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
-    const uint8_t *p = guide + (size_t)f * fs + (size_t)y * step + (size_t)x * 3;
-    const double I0 = normv(p[0], mn, mx), I1 = normv(p[1], mn, mx), I2 = normv(p[2], mn, mx);
-    const double rbase = 1.0 / box_base(y, x, H, W, r);
-#pragma unroll
-    for (int ip = 0; ip < NP; ++ip) {
-        const double *sr = s_rows + (size_t)(4 * ip) * LW;
-        const double a0 = win(sr, x, x0, r, W), a1 = win(sr + LW, x, x0, r, W);
-        const double a2 = win(sr + 2 * (size_t)LW, x, x0, r, W), bb = win(sr + 3 * (size_t)LW, x, x0, r, W);
-        Q[((size_t)f * NP + ip) * n + (size_t)y * W + x] = (a0 * I0 + a1 * I1 + a2 * I2 + bb) * rbase;
-    }
-}
-
-// ---- streaming strip form of the guided filter ------------------------------------------------------
-// A block owns a strip of 256 columns (TS = 256 - 2r outputs plus an r-column halo on each side) and walks
-// down the rows.  Every thread keeps the vertical sliding-window sums of its own column in registers; for each
-// row the 256 column sums of every plane go to LDS, are prefix-scanned across the strip, and the interior
-// columns take their box sums as differences, solve, and write a, b (or q).  The 13-17 intermediate
-// box-sum planes of the separable form never exist in HBM.  Columns outside the image contribute zeros, which
-// is exactly the reference's "valid part of the window" (guidedfilter.py:39-41,67).
-template <int NP>
-__global__ __launch_bounds__(256) void k_gf_strip_solve(const uint8_t *__restrict__ guide, size_t step, size_t fs,
-                                                        const int *__restrict__ gnorm, int gnorm_stride,
-                                                        const double *__restrict__ P /*[F][NP][H][W]*/,
-                                                        double *__restrict__ AB /*[F*NP][4][H][W]*/, int H, int W, int r,
-                                                        double eps, int TS, int rows_per_chunk)
-{
-    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    constexpr int NF = 4 * NP;
-    double *sf = s_dyn;                                                     // [NF][256]
-    uint32_t *si = reinterpret_cast<uint32_t *>(s_dyn + (size_t)NF * 256);  // [9][256]
-    __shared__ double s_tot[(9 + NF) * 64];
-    __shared__ double s_T[256];
-    const int t = threadIdx.x, f = blockIdx.z;
-    const int x = (int)blockIdx.x * TS - r + t;
-    const bool inimg = x >= 0 && x < W;
-    const size_t n = (size_t)H * W;
-    const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
-    s_T[t] = t >= mn ? normv(t, mn, mx) : 0.0;
-    __syncthreads();
-    const uint8_t *g = guide + (size_t)f * fs + (size_t)(inimg ? x : 0) * 3;
-    const double *pin = P + (size_t)f * NP * n + (inimg ? x : 0);
-    uint32_t gi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    double pf[NP][4];
-#pragma unroll
-    for (int ip = 0; ip < NP; ++ip) { pf[ip][0] = pf[ip][1] = pf[ip][2] = pf[ip][3] = 0.0; }
-    auto accum = [&](int yy, bool add) {
-        if (!inimg) return;
-        const uint8_t *p = g + (size_t)yy * step;
-        const uint32_t a = (uint32_t)max((int)p[0] - mn, 0), b = (uint32_t)max((int)p[1] - mn, 0), c = (uint32_t)max((int)p[2] - mn, 0);
-        const uint32_t v[9] = {a, b, c, a * a, a * b, a * c, b * b, b * c, c * c};
-#pragma unroll
-        for (int k = 0; k < 9; ++k) gi[k] = add ? gi[k] + v[k] : gi[k] - v[k];
-        const double Ta = s_T[p[0]], Tb = s_T[p[1]], Tc = s_T[p[2]];
-        const double sign = add ? 1.0 : -1.0;
-#pragma unroll
-        for (int ip = 0; ip < NP; ++ip) {
-            const double pv = pin[(size_t)ip * n + (size_t)yy * W];
-            pf[ip][0] += sign * pv; pf[ip][1] += sign * (Ta * pv); pf[ip][2] += sign * (Tb * pv); pf[ip][3] += sign * (Tc * pv);
-        }
-    };
-    const int y0 = blockIdx.y * rows_per_chunk, y1 = min(H, y0 + rows_per_chunk);
-    for (int yy = max(0, y0 - r); yy <= min(H - 1, y0 + r); ++yy) accum(yy, true);
-    const double rdd = 1.0 / (double)(mx - mn);
-    const bool interior = t >= r && t < r + TS && inimg;
-    for (int y = y0; y < y1; ++y) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) si[k * 256 + t] = gi[k];
-#pragma unroll
-        for (int ip = 0; ip < NP; ++ip)
-#pragma unroll
-            for (int k = 0; k < 4; ++k) sf[(ip * 4 + k) * 256 + t] = pf[ip][k];
-        __syncthreads();
-        scan_planes<9, NF>(si, sf, s_tot, 256);
-        if (interior) {
-            // window = strip columns [t-r, t+r]; columns outside the image hold zeros
-            const int hi = t + r, lo = t - r - 1;
-            const double rbase = 1.0 / box_base(y, x, H, W, r);
-            const double r1 = rdd * rbase, r2 = (rdd * rdd) * rbase;
-            double gs[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const uint32_t wsum = si[k * 256 + hi] - (lo >= 0 ? si[k * 256 + lo] : 0u);
-                gs[k] = (double)wsum * (k < 3 ? r1 : r2);
-            }
-            const double m0 = gs[0], m1 = gs[1], m2 = gs[2];
-            const double s00 = gs[3] - m0 * m0 + eps, s01 = gs[4] - m0 * m1, s02 = gs[5] - m0 * m2;
-            const double s11 = gs[6] - m1 * m1 + eps, s12 = gs[7] - m1 * m2, s22 = gs[8] - m2 * m2 + eps;
-            const double k00 = s11 * s22 - s12 * s12, k01 = s02 * s12 - s01 * s22, k02 = s01 * s12 - s02 * s11;
-            const double k11 = s00 * s22 - s02 * s02, k12 = s01 * s02 - s00 * s12, k22 = s00 * s11 - s01 * s01;
-            const double rdet = 1.0 / (s00 * k00 + s01 * k01 + s02 * k02);
-            const size_t i = (size_t)y * W + x;
-#pragma unroll
-            for (int ip = 0; ip < NP; ++ip) {
-                double w4[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    w4[k] = (sf[(ip * 4 + k) * 256 + hi] - (lo >= 0 ? sf[(ip * 4 + k) * 256 + lo] : 0.0)) * rbase;
-                const double mp = w4[0], c0 = w4[1] - m0 * mp, c1 = w4[2] - m1 * mp, c2 = w4[3] - m2 * mp;
-                const double a0 = (c0 * k00 + c1 * k01 + c2 * k02) * rdet;
-                const double a1 = (c0 * k01 + c1 * k11 + c2 * k12) * rdet;
-                const double a2 = (c0 * k02 + c1 * k12 + c2 * k22) * rdet;
-                double *o = AB + ((size_t)f * NP + ip) * 4 * n;
-                o[i] = a0; o[n + i] = a1; o[2 * n + i] = a2;
-                o[3 * n + i] = mp - a0 * m0 - a1 * m1 - a2 * m2;
-            }
-        }
-        __syncthreads();
-        if (y + r + 1 < H) accum(y + r + 1, true);
-        if (y - r >= 0) accum(y - r, false);
-    }
-}
-
-template <int NP>
-__global__ __launch_bounds__(256) void k_gf_strip_final(const double *__restrict__ AB /*[F*NP][4][H][W]*/,
-                                                        const uint8_t *__restrict__ guide, size_t step, size_t fs,
-                                                        const int *__restrict__ gnorm, int gnorm_stride,
-                                                        double *__restrict__ Q /*[F*NP][H][W]*/, int H, int W, int r, int TS,
-                                                        int rows_per_chunk)
-{
-    extern __shared__ __attribute__((aligned(16))) double s_dyn[];
-    constexpr int NF = 4 * NP;
-    double *sf = s_dyn;                                                     // [NF][256]
-    __shared__ double s_tot[NF * 64];
-    const int t = threadIdx.x, f = blockIdx.z;
-    const int x = (int)blockIdx.x * TS - r + t;
-    const bool inimg = x >= 0 && x < W;
-    const size_t n = (size_t)H * W;
-    const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
-    const double *ab = AB + (size_t)f * NF * n + (inimg ? x : 0);
-    double acc[NF];
-#pragma unroll
-    for (int k = 0; k < NF; ++k) acc[k] = 0.0;
-    auto accum = [&](int yy, double sign) {
-        if (!inimg) return;
-#pragma unroll
-        for (int k = 0; k < NF; ++k) acc[k] += sign * ab[(size_t)k * n + (size_t)yy * W];
-    };
-    const int y0 = blockIdx.y * rows_per_chunk, y1 = min(H, y0 + rows_per_chunk);
-    for (int yy = max(0, y0 - r); yy <= min(H - 1, y0 + r); ++yy) accum(yy, 1.0);
-    const bool interior = t >= r && t < r + TS && inimg;
-    const uint8_t *gb = guide + (size_t)f * fs + (size_t)(inimg ? x : 0) * 3;
-    for (int y = y0; y < y1; ++y) {
-#pragma unroll
-        for (int k = 0; k < NF; ++k) sf[k * 256 + t] = acc[k];
-        __syncthreads();
-        scan_planes<0, NF>(nullptr, sf, s_tot, 256);
-        if (interior) {
-            const int hi = t + r, lo = t - r - 1;
-            const double rbase = 1.0 / box_base(y, x, H, W, r);
-            const uint8_t *p = gb + (size_t)y * step;
-            const double I0 = normv(p[0], mn, mx), I1 = normv(p[1], mn, mx), I2 = normv(p[2], mn, mx);
-#pragma unroll
-            for (int ip = 0; ip < NP; ++ip) {
-                double w4[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    w4[k] = sf[(ip * 4 + k) * 256 + hi] - (lo >= 0 ? sf[(ip * 4 + k) * 256 + lo] : 0.0);
-                Q[((size_t)f * NP + ip) * n + (size_t)y * W + x] = (w4[0] * I0 + w4[1] * I1 + w4[2] * I2 + w4[3]) * rbase;
-            }
-        }
-        __syncthreads();
-        if (y + r + 1 < H) accum(y + r + 1, 1.0);
-        if (y - r >= 0) accum(y - r, -1.0);
     }
 }
 
@@ -991,86 +552,17 @@ __global__ void k_get_B(const double *sc, const int *si, double *B, int *idx, in
 struct DzBufs {
     int *si; double *sc; double *part; int *pidx;
     uint8_t *u8planes;       // [F][3][H][W] window max/min
-    double *P, *VG, *VP, *AB, *Q;
+    double *P, *AB, *Q;
 };
 
 // guided filter with a normalised-u8 guide: P [F][np] planes -> Q [F][np] planes
+// The guided filter itself lives in guided_filter_ws.hip (wave-strip kernels).
 int guided_filter_u8(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs, const int *gnorm, int gstride,
-                     const double *P, double *Q, double *VG, double *VP, double *AB, int F, int np, int H, int W,
-                     int r, double eps)
+                     const double *P, double *Q, double *AB, int F, int np, int H, int W, int r, double eps)
 {
     UWIP_REQUIRE(ctx, H >= 2 * r + 1 && W >= 2 * r + 1, "guided filter needs rows, cols >= 2r+1 (guidedfilter.py:39-41)");
-    // row chunks per column: every chunk re-reads a 2r+1 row window and adds one more lag window to the cache
-    // footprint, so use one chunk whenever the batch alone yields >= ~2048 blocks
-    auto chunks_for = [&](int zcount) {
-        const size_t blocks1 = (size_t)uwip_cdiv(W, 256) * zcount;
-        const int want = (int)((2048 + blocks1 - 1) / blocks1);
-        return std::max(1, std::min(std::min(want, 8), std::max(1, H / 64)));
-    };
-    auto rpc_for = [&](int zcount) { const int c = chunks_for(zcount); return (H + c - 1) / c; };
-    const unsigned xb = uwip_cdiv(W, 256);
-    UWIP_REQUIRE(ctx, np == 1 || np == 2, "np must be 1 or 2");
-    UWIP_REQUIRE(ctx, H <= 65535 && F <= 65535, "too many rows/frames for one launch");
-    const char *env_strip = getenv("UWIP_GF_STRIP");
-    // UWIP_GF_STRIP: unset / "ws" = wave-strip kernels (guided_filter_ws.hip), N > 0 = block-strip kernels with N row
-    // chunks, 0 = separable form (box-sum planes in HBM; the only form for 2r > 192)
-    if ((!env_strip || env_strip[0] == 'w') && 2 * r <= 192)
-        return uwip_gf_wave_strip(ctx, guide, step, fs, gnorm, gstride, P, Q, AB, F, np, H, W, r, eps);
-    const int strip_mode = env_strip ? atoi(env_strip) : 0;
-    if (strip_mode > 0 && 2 * r < 200) {
-        // streaming strip form: two kernels, no intermediate box-sum planes
-        const int TS = 256 - 2 * r;
-        const int nchunk = std::max(1, std::min(strip_mode, std::max(1, H / 64)));
-        const int rpc = (H + nchunk - 1) / nchunk;
-        const dim3 gs(uwip_cdiv(W, TS), uwip_cdiv(H, rpc), (unsigned)F);
-        UWIP_REQUIRE(ctx, (uint64_t)256 * (2 * r + 1) * 65025ull < (1ull << 32), "window too large for the exact integer guide sums");
-        {
-            uwip_kscope ks(ctx, "k_gf_strip_solve");
-            const size_t lds = (size_t)(4 * np) * 256 * sizeof(double) + (size_t)9 * 256 * sizeof(uint32_t);
-            if (np == 2) k_gf_strip_solve<2><<<gs, 256, lds, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc);
-            else k_gf_strip_solve<1><<<gs, 256, lds, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc);
-        }
-        {
-            uwip_kscope ks(ctx, "k_gf_strip_final");
-            const size_t lds = (size_t)(4 * np) * 256 * sizeof(double);
-            if (np == 2) k_gf_strip_final<2><<<gs, 256, lds, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, Q, H, W, r, TS, rpc);
-            else k_gf_strip_final<1><<<gs, 256, lds, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, Q, H, W, r, TS, rpc);
-        }
-        UWIP_HIP(ctx, hipGetLastError());
-        return UWIP_OK;
-    }
-    const int LW = HSEG + 2 * r + 1;
-    const size_t lds_solve = (size_t)(4 * np) * LW * sizeof(double) + (size_t)9 * LW * sizeof(uint32_t);
-    const size_t lds_final = (size_t)(4 * np) * LW * sizeof(double);
-    UWIP_REQUIRE(ctx, (uint64_t)LW * (2 * r + 1) * 65025ull < (1ull << 32), "window too large for the exact integer guide sums");
-    UWIP_REQUIRE(ctx, lds_solve <= 64 * 1024 - 256 && LW <= 512 && LW <= RUNMAX * (256 / (9 + 4 * np)),
-                 "radius too large for the fused horizontal pass");
-    const dim3 gh(uwip_cdiv(W, HSEG), (unsigned)H, (unsigned)F);
-    UWIP_REQUIRE(ctx, H <= 65535 && F <= 65535, "too many rows/frames for one launch");
-    {
-        uwip_kscope ks(ctx, "k_vsum<guide>");
-        k_vsum_guide_u32<<<dim3(xb, uwip_cdiv(H, rpc_for(F)), F), 256, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, (uint32_t *)VG, H, W, r, rpc_for(F));
-    }
-    {
-        uwip_kscope ks(ctx, "k_vsum<p>");
-        k_vsum<1><<<dim3(xb, uwip_cdiv(H, rpc_for(F * np)), F * np), 256, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, VP, H, W, r, rpc_for(F * np), np);
-    }
-    {
-        uwip_kscope ks(ctx, "k_gf_solve_h");
-        if (np == 2) k_gf_solve_h<2><<<gh, 256, lds_solve, ctx->stream>>>((const uint32_t *)VG, VP, AB, H, W, r, eps, gnorm, gstride);
-        else k_gf_solve_h<1><<<gh, 256, lds_solve, ctx->stream>>>((const uint32_t *)VG, VP, AB, H, W, r, eps, gnorm, gstride);
-    }
-    {
-        uwip_kscope ks(ctx, "k_vsum<plane>");
-        k_vsum<2><<<dim3(xb, uwip_cdiv(H, rpc_for(F * np * 4)), F * np * 4), 256, 0, ctx->stream>>>(nullptr, 0, 0, nullptr, 0, AB, VP, H, W, r, rpc_for(F * np * 4), np);
-    }
-    {
-        uwip_kscope ks(ctx, "k_gf_final_h");
-        if (np == 2) k_gf_final_h<2><<<gh, 256, lds_final, ctx->stream>>>(VP, guide, step, fs, gnorm, gstride, Q, H, W, r);
-        else k_gf_final_h<1><<<gh, 256, lds_final, ctx->stream>>>(VP, guide, step, fs, gnorm, gstride, Q, H, W, r);
-    }
-    UWIP_HIP(ctx, hipGetLastError());
-    return UWIP_OK;
+    UWIP_REQUIRE(ctx, r <= 96, "guided filter radius > 96 is not supported");
+    return uwip_gf_wave_strip(ctx, guide, step, fs, gnorm, gstride, P, Q, AB, F, np, H, W, r, eps);
 }
 
 int alloc_bufs(uwip_ctx *ctx, int F, int H, int W, DzBufs *b)
@@ -1082,11 +574,9 @@ int alloc_bufs(uwip_ctx *ctx, int F, int H, int W, DzBufs *b)
     b->pidx = (int *)uwip_ws(ctx, "dz.pidx", sizeof(int) * 2 * RED_BLOCKS * F);
     b->u8planes = (uint8_t *)uwip_ws(ctx, "dz.u8", (size_t)4 * n * F);
     b->P = (double *)uwip_ws(ctx, "dz.P", sizeof(double) * 2 * n * F);
-    b->VG = (double *)uwip_ws(ctx, "dz.VG", sizeof(double) * 9 * n * F);
-    b->VP = (double *)uwip_ws(ctx, "dz.VP", sizeof(double) * 8 * n * F);
     b->AB = (double *)uwip_ws(ctx, "dz.AB", sizeof(double) * 8 * n * F);
     b->Q = (double *)uwip_ws(ctx, "dz.Q", sizeof(double) * 2 * n * F);
-    if (!b->si || !b->sc || !b->part || !b->pidx || !b->u8planes || !b->P || !b->VG || !b->VP || !b->AB || !b->Q)
+    if (!b->si || !b->sc || !b->part || !b->pidx || !b->u8planes || !b->P || !b->AB || !b->Q)
         return UWIP_ERR_NOMEM;
     return UWIP_OK;
 }
@@ -1199,7 +689,7 @@ UWIP_API int uwip_guided_filter(uwip_ctx *ctx, const uwip_batch_u8 *guide, const
                                                                guide->frame_stride, H, W, b.si);
     }
     return guided_filter_u8(ctx, (const uint8_t *)guide->data, guide->step, guide->frame_stride, b.si, SI_COUNT, d_p,
-                            d_q, b.VG, b.VP, b.AB, F, 1, H, W, r, eps);
+                            d_q, b.AB, F, 1, H, W, r, eps);
 }
 
 UWIP_API int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batch_u8 *out, int w, int flags,
@@ -1227,7 +717,7 @@ UWIP_API int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batc
     if (rc) return rc;
     rc = run_transmission(ctx, in, b, tmin, nullptr);
     if (rc) return rc;
-    rc = guided_filter_u8(ctx, img, in->step, in->frame_stride, b.si, SI_COUNT, b.P, b.Q, b.VG, b.VP, b.AB, F, 2, H, W, r, eps);
+    rc = guided_filter_u8(ctx, img, in->step, in->frame_stride, b.si, SI_COUNT, b.P, b.Q, b.AB, F, 2, H, W, r, eps);
     if (rc) return rc;
     if (d_refined_t)
         UWIP_HIP(ctx, hipMemcpyAsync(d_refined_t, b.Q, sizeof(double) * 2 * n * F, hipMemcpyDeviceToDevice, ctx->stream));
@@ -1263,7 +753,7 @@ UWIP_API int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batc
         uwip_kscope ks(ctx, "k_exp_S");
         k_exp_S<<<dim3(512, F), 256, 0, ctx->stream>>>(YI, YJ, b.si, n, S, guard);
     }
-    rc = guided_filter_u8(ctx, YI, (size_t)W * 3, n * 3, b.si + SI_YIMN, SI_COUNT, S, RS, b.VG, b.VP, b.AB, F, 1, H, W, r, eps);
+    rc = guided_filter_u8(ctx, YI, (size_t)W * 3, n * 3, b.si + SI_YIMN, SI_COUNT, S, RS, b.AB, F, 1, H, W, r, eps);
     if (rc) return rc;
     {
         uwip_kscope ks(ctx, "k_exp_out");
