@@ -79,3 +79,46 @@ def test_config3_dehaze_histretch_4k(orc):
     exp, _ = orc.histretch(ah, "RGB")
     assert np.array_equal(a.cpu().numpy(), exp)
     ctx.close()
+
+
+def test_config5_full_pipe_4k(orc):
+    """BASELINE config 5: the full pipe on 3840x2160 frames.  The oracle continues from the device's own
+    dehaze output (see the module docstring); every later stage must match it exactly, and a batch of two
+    must equal the frames run one at a time."""
+    F, H, W = 2, 2160, 3840
+    frames = synth.uw_stream(0, F, H, W)
+    pipe = FramePipe(0, F, H, W)
+    src = torch.from_numpy(frames).cuda()
+    pipe.stage_dehaze(src)
+    torch.cuda.synchronize()
+    dehazed = pipe.work.cpu().numpy().copy()
+    pipe.stage_histretch()
+    pipe.stage_aclahe()
+    pipe.stage_overlap()
+    torch.cuda.synchronize()
+    out = pipe.work.cpu().numpy().copy()
+    ratios = pipe.ratio.cpu().numpy().copy()
+    params = list(pipe.params)
+    exp = []
+    for f in range(F):
+        st, _ = orc.histretch(dehazed[f], "RGB")
+        v = orc.bgr_to_v(st)
+        if f == 0:   # the 255-evaluation sweep of the oracle takes a while at this size: one frame
+            assert params[f] == aclahe.select_parameters(orc.sweep(v))
+        bs, cl = params[f]
+        e = orc.hsv_replace_v(st, orc.clahe(v, float(cl), bs, bs))
+        assert np.array_equal(out[f], e), f
+        exp.append(e)
+    er, _, _ = orc.calcOverlap(exp[0], exp[1], W, H, seed=1)
+    assert abs(ratios[1] - er) <= 1e-6
+    pipe.close()
+    # one frame at a time
+    single = FramePipe(0, 1, H, W)
+    for f in range(F):
+        o, r = single.run(src[f:f + 1])
+        torch.cuda.synchronize()
+        assert np.array_equal(o.cpu().numpy()[0], out[f])
+        assert single.params[0] == params[f]
+        if f > 0:
+            assert abs(float(r.cpu()[0]) - ratios[f]) <= 1e-6
+    single.close()
