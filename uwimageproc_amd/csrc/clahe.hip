@@ -395,6 +395,21 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
             const float tyf = (float)y * inv_th - 0.5f;
             const float ya = tyf - floorf(tyf), ya1 = 1.0f - ya;
             const f32x2 xa1v = {xa1, xa1}, xav = {xa, xa}, yv = {ya1, ya};
+            if (diffmask == (1u << SWEEP_GROUP) - 1u) {
+                // every clip limit has its own LUTs (the common case): no branches, so the 17 LUT reads go out
+                // together and their evaluations interleave
+                uint32_t pk[SWEEP_GROUP];
+#pragma unroll
+                for (int c = 0; c < SWEEP_GROUP; ++c) pk[c] = s_pack[c * 256 + v];
+#pragma unroll
+                for (int c = 0; c < SWEEP_GROUP; ++c) {
+                    const f32x2 ac = {(float)(pk[c] & 255u), (float)((pk[c] >> 16) & 255u)};
+                    const f32x2 bd = {(float)((pk[c] >> 8) & 255u), (float)(pk[c] >> 24)};
+                    const f32x2 t = (ac * xa1v + bd * xav) * yv;
+                    atomicAdd(&my_hist[c * 256 + __builtin_amdgcn_cvt_pk_u8_f32(t.x + t.y, 0, 0u)], 1u);
+                }
+                continue;
+            }
             uint32_t o = 0;
 #pragma unroll
             for (int c = 0; c < SWEEP_GROUP; ++c) {
