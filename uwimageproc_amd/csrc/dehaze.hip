@@ -553,6 +553,7 @@ struct DzBufs {
     int *si; double *sc; double *part; int *pidx;
     uint8_t *u8planes;       // [F][3][H][W] window max/min
     double *P, *AB, *Q;
+    uint8_t *u8min = nullptr;   // window-min planes when the fused 15x15 kernel produced them already
 };
 
 // guided filter with a normalised-u8 guide: P [F][np] planes -> Q [F][np] planes
@@ -591,7 +592,7 @@ int check_in(uwip_ctx *ctx, const uwip_batch_u8 *in, int w)
 }
 
 // stages D0-D1: scalars + background light
-int run_bglight(uwip_ctx *ctx, const uwip_batch_u8 *in, int w, DzBufs &b, const double *d_B_inject)
+int run_bglight(uwip_ctx *ctx, const uwip_batch_u8 *in, int w, DzBufs &b, const double *d_B_inject, bool also_min = false)
 {
     const int F = in->frames, H = in->rows, W = in->cols;
     const uint8_t *img = (const uint8_t *)in->data;
@@ -601,7 +602,18 @@ int run_bglight(uwip_ctx *ctx, const uwip_batch_u8 *in, int w, DzBufs &b, const 
         k_dz_minmax<<<dim3(RED_BLOCKS, F), 256, 0, ctx->stream>>>(img, in->step, in->frame_stride, H, W, b.si);
     }
     const int pad = w / 2;
-    {
+    b.u8min = nullptr;
+    if (uwip_winfilter15_ok(img, in->step, in->frame_stride, H, W, w)) {
+        // one pass for the window maximum and (when the transmission follows) the window minimum
+        uint8_t *mn = nullptr;
+        if (also_min) {
+            mn = (uint8_t *)uwip_ws(ctx, "dz.u8min", (size_t)3 * H * W * F);
+            if (!mn) return UWIP_ERR_NOMEM;
+        }
+        const int rc = uwip_winfilter15(ctx, img, in->step, in->frame_stride, F, H, W, b.u8planes, mn);
+        if (rc) return rc;
+        b.u8min = mn;
+    } else {
         const size_t lds = (size_t)3 * (WF_TH + w - 1) * (WF_TW + w - 1) + (size_t)3 * (WF_TH + w - 1) * WF_TW;
         uwip_kscope ks(ctx, "k_winfilter<max>");
         k_winfilter<true><<<dim3(uwip_cdiv(W, WF_TW), uwip_cdiv(H, WF_TH), F), 256, lds, ctx->stream>>>(
@@ -622,15 +634,22 @@ int run_transmission(uwip_ctx *ctx, const uwip_batch_u8 *in, DzBufs &b, double t
     const int F = in->frames, H = in->rows, W = in->cols;
     const uint8_t *img = (const uint8_t *)in->data;
     const int w = 15, pad = 7;                                   // refined_t drops w (BGDehaze.py:52, B-10)
-    {
-        const size_t lds = (size_t)3 * (WF_TH + w - 1) * (WF_TW + w - 1) + (size_t)3 * (WF_TH + w - 1) * WF_TW;
-        uwip_kscope ks(ctx, "k_winfilter<min>");
-        k_winfilter<false><<<dim3(uwip_cdiv(W, WF_TW), uwip_cdiv(H, WF_TH), F), 256, lds, ctx->stream>>>(
-            img, in->step, in->frame_stride, H, W, w, pad, b.u8planes);
+    const uint8_t *mnp = b.u8min;
+    if (!mnp) {
+        mnp = b.u8planes;
+        if (uwip_winfilter15_ok(img, in->step, in->frame_stride, H, W, w)) {
+            const int rc = uwip_winfilter15(ctx, img, in->step, in->frame_stride, F, H, W, nullptr, b.u8planes);
+            if (rc) return rc;
+        } else {
+            const size_t lds = (size_t)3 * (WF_TH + w - 1) * (WF_TW + w - 1) + (size_t)3 * (WF_TH + w - 1) * WF_TW;
+            uwip_kscope ks(ctx, "k_winfilter<min>");
+            k_winfilter<false><<<dim3(uwip_cdiv(W, WF_TW), uwip_cdiv(H, WF_TH), F), 256, lds, ctx->stream>>>(
+                img, in->step, in->frame_stride, H, W, w, pad, b.u8planes);
+        }
     }
     {
         uwip_kscope ks(ctx, "k_transmission");
-        k_transmission<<<dim3(512, F), 256, 0, ctx->stream>>>(b.u8planes, H, W, w, pad, b.si, b.sc, tmin, b.P, d_traw);
+        k_transmission<<<dim3(512, F), 256, 0, ctx->stream>>>(mnp, H, W, w, pad, b.si, b.sc, tmin, b.P, d_traw);
     }
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
@@ -665,7 +684,7 @@ UWIP_API int uwip_dehaze_transmission(uwip_ctx *ctx, const uwip_batch_u8 *in, co
     DzBufs b;
     rc = alloc_bufs(ctx, in->frames, in->rows, in->cols, &b);
     if (rc) return rc;
-    rc = run_bglight(ctx, in, 15, b, d_B);
+    rc = run_bglight(ctx, in, 15, b, d_B, true);
     if (rc) return rc;
     return run_transmission(ctx, in, b, 0.2, d_t);
 }
@@ -713,7 +732,7 @@ UWIP_API int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batc
     rc = alloc_bufs(ctx, F, H, W, &b);
     if (rc) return rc;
     const uint8_t *img = (const uint8_t *)in->data;
-    rc = run_bglight(ctx, in, w, b, d_B_inject);
+    rc = run_bglight(ctx, in, w, b, d_B_inject, w == 15);
     if (rc) return rc;
     rc = run_transmission(ctx, in, b, tmin, nullptr);
     if (rc) return rc;
