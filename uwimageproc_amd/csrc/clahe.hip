@@ -321,6 +321,7 @@ struct CellItem {
 // a block is 1024 threads (16 waves share one set of packed LUTs + replicas: 85 KB of LDS, one block per CU).
 constexpr int SWEEP_THREADS = 512;
 constexpr int SWEEP_REP = 2;
+constexpr int SWEEP_SPREAD = 8;    // multiple of SWEEP_THREADS / 64
 constexpr int SWEEP_RSTRIDE = SWEEP_GROUP * 256 + 8;   // +8 words: equal bins of different replicas fall in different LDS banks
 __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__restrict__ src, size_t step,
                                                      size_t fstride, int gx, int gy, float inv_tw,
@@ -385,11 +386,18 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
         };
         int xn = 0, yn = 0;
         uint32_t vnext = 0;
-        if (tid < npix) { locate(tid, xn, yn); vnext = fb[(size_t)yn * step + xn]; }
-        for (int p = tid; p < npix; p += SWEEP_THREADS) {
+        // The 64 pixels of one LDS-atomic instruction are SWEEP_SPREAD apart (lane i of wave w takes pixel
+        // SWEEP_SPREAD*i + w + 8m of every 64*SWEEP_SPREAD), so fewer of them fall into the same output bin than 64
+        // neighbours of a smooth frame would.
+        constexpr int MS = SWEEP_SPREAD / (SWEEP_THREADS / 64);
+        auto pix_of = [&](int t) { return (t / MS) * (64 * SWEEP_SPREAD) + (tid & 63) * SWEEP_SPREAD + (tid >> 6) + (SWEEP_THREADS / 64) * (t % MS); };
+        int t = 0, p = pix_of(0);
+        if (p < npix) { locate(p, xn, yn); vnext = fb[(size_t)yn * step + xn]; }
+        for (; p < npix;) {
             const int x = xn, y = yn;
             const uint32_t v = vnext;
-            if (p + SWEEP_THREADS < npix) { locate(p + SWEEP_THREADS, xn, yn); vnext = fb[(size_t)yn * step + xn]; }
+            p = pix_of(++t);
+            if (p < npix) { locate(p, xn, yn); vnext = fb[(size_t)yn * step + xn]; }
             const float txf = (float)x * inv_tw - 0.5f;
             const float xa = txf - floorf(txf), xa1 = 1.0f - xa;
             const float tyf = (float)y * inv_th - 0.5f;
