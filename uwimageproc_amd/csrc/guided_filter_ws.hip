@@ -64,6 +64,21 @@ __device__ __forceinline__ void wave_lds_fence()
 
 __device__ __forceinline__ int byte_of(const uint32_t (&g)[3], int k) { return (int)((g[k >> 2] >> ((k & 3) * 8)) & 0xffu); }
 
+// Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2).  Give every XCD a contiguous range of
+// the logical (strip, y, z) index space instead, so that neighbouring strips -- which share 2r halo columns -- run
+// on the same XCD at about the same time and the second reader hits in L2.  Returns false for the padding blocks.
+__device__ __forceinline__ bool xcd_decode(unsigned nx, unsigned ny, unsigned nz, unsigned &bx, unsigned &by, unsigned &bz)
+{
+    const unsigned total = nx * ny * nz, per = (total + 7u) / 8u;
+    const unsigned m = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (m >= total) return false;
+    bx = m % nx;
+    const unsigned t = m / nx;
+    by = t % ny;
+    bz = t / ny;
+    return true;
+}
+
 struct StripGeom {
     int l, x0;           // lane, image column of the lane's first column
     bool in[4];          // column inside the image
@@ -112,16 +127,18 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
                                                     const int *__restrict__ gnorm, int gnorm_stride,
                                                     const double *__restrict__ P /*[F][NP][H][W]*/,
                                                     double *__restrict__ AB /*[F*NP][4][H][W]: column prefix sums of a, b*/,
-                                                    int H, int W, int r, double eps, int TS, int rpc, int fdiv)
+                                                    int H, int W, int r, double eps, int TS, int rpc, int fdiv, uint3 nb)
 {
 #pragma clang fp contract(fast)
     __shared__ uint4 s_u4[2 * 4 * 64];
     __shared__ uint32_t s_u1[4 * 64];
     __shared__ double2 s_d2[NP * 2 * 4 * 64];
+    unsigned bx, by, bz;
+    if (!xcd_decode(nb.x, nb.y, nb.z, bx, by, bz)) return;
     StripGeom sg;
-    sg.init(blockIdx.x, TS, r, W);
-    // blockIdx.z counts groups of NP p-planes; fdiv of them share a frame (fdiv = np / NP)
-    const int l = sg.l, zg = blockIdx.z, f = zg / fdiv;
+    sg.init(bx, TS, r, W);
+    // bz counts groups of NP p-planes; fdiv of them share a frame (fdiv = np / NP)
+    const int l = sg.l, zg = bz, f = zg / fdiv;
     const size_t n = (size_t)H * W;
     const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
     const uint32_t fillw = (uint32_t)mn * 0x01010101u;
@@ -193,7 +210,7 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
     const std::true_type ADD{};
     const std::false_type SUB{};
 
-    const int y0 = blockIdx.y * rpc, y1 = min(H, y0 + rpc);
+    const int y0 = by * rpc, y1 = min(H, y0 + rpc);
     const double rdd = 1.0 / (double)(mx - mn);
     // warm-up: rows [max(0, y0 - r), y0 + r) in batches of four loads
     int v = max(y0 - r, 0);
@@ -332,20 +349,22 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
                                                     const uint8_t *__restrict__ guide, size_t step, size_t fs,
                                                     const int *__restrict__ gnorm, int gnorm_stride, int NP,
                                                     double *__restrict__ Q /*[Z][H][W]*/, int H, int W, int r, int TS,
-                                                    int rpc /*rows per chunk of S*/, int spw /*chains per wave*/)
+                                                    int rpc /*rows per chunk of S*/, int spw /*chains per wave*/, uint3 nb)
 {
 #pragma clang fp contract(fast)
     __shared__ double2 s_d2[2 * 4 * 64];
+    unsigned bx, by, bz;
+    if (!xcd_decode(nb.x, nb.y, nb.z, bx, by, bz)) return;
     StripGeom sg;
-    sg.init(blockIdx.x, TS, r, W);
-    const int l = sg.l, z = blockIdx.z, f = z / NP;
+    sg.init(bx, TS, r, W);
+    const int l = sg.l, z = bz, f = z / NP;
     const size_t n = (size_t)H * W;
     const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
     const uint8_t *gf = guide + (size_t)f * fs;
     const double *sp = S + (size_t)z * 4 * n;
     const int D = 2 * r + 1;
-    const int s_end = min(min(D, H), (int)(blockIdx.y + 1) * spw);
-    int s = blockIdx.y * spw, y = s;
+    const int s_end = min(min(D, H), (int)(by + 1) * spw);
+    int s = by * spw, y = s;
     if (s >= s_end) return;
 
     auto load_row = [&](int yy, FinalRow &R) {
@@ -476,7 +495,7 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
     UWIP_REQUIRE(ctx, np == 1 || np == 2, "np must be 1 or 2");
     UWIP_REQUIRE(ctx, r >= 1 && 2 * r <= 192, "radius out of range for the 256-column strip");
     UWIP_REQUIRE(ctx, H >= 2 * r + 1 && W >= 2 * r + 1, "guided filter needs rows, cols >= 2r+1");
-    UWIP_REQUIRE(ctx, H <= 65535 && (size_t)F * np <= 65535, "too many rows/frames for one launch");
+    UWIP_REQUIRE(ctx, (uint64_t)uwip_cdiv(W, 256 - 2 * r) * 16 * F * np < (1ull << 31) && (uint64_t)uwip_cdiv(W, 256 - 2 * r) * (2 * r + 1) * F * np < (1ull << 31), "too many blocks for one launch");
     UWIP_REQUIRE(ctx, (uint64_t)256 * (2 * r + 1) * 65025ull < (1ull << 32), "window too large for the exact integer guide sums");
     const int TS = 256 - 2 * r, D = 2 * r + 1;
     const unsigned strips = uwip_cdiv(W, TS);
@@ -517,15 +536,16 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
     int rpc = (H + c - 1) / c;
     if (rpc < D) rpc = D;
     {
-        const dim3 grid(strips, uwip_cdiv(H, rpc), zs);
+        const uint3 nb = make_uint3(strips, uwip_cdiv(H, rpc), zs);
+        const unsigned grid = 8u * ((nb.x * nb.y * nb.z + 7u) / 8u);
         uwip_kscope ks(ctx, "k_gf_ws_solve");
         const int fdiv = np / knp;
         if (knp == 2) {
-            if (vec) k_gf_ws_solve<2, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv);
-            else k_gf_ws_solve<2, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv);
+            if (vec) k_gf_ws_solve<2, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb);
+            else k_gf_ws_solve<2, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb);
         } else {
-            if (vec) k_gf_ws_solve<1, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv);
-            else k_gf_ws_solve<1, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv);
+            if (vec) k_gf_ws_solve<1, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb);
+            else k_gf_ws_solve<1, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb);
         }
     }
     {
@@ -538,10 +558,11 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
         if (e && atoi(e) > 0) groups = atoi(e);
         groups = std::max(1, std::min(groups, nchain));
         const int spw = (nchain + groups - 1) / groups;
-        const dim3 grid(strips, uwip_cdiv(nchain, spw), Z);
+        const uint3 nb = make_uint3(strips, uwip_cdiv(nchain, spw), Z);
+        const unsigned grid = 8u * ((nb.x * nb.y * nb.z + 7u) / 8u);
         uwip_kscope ks(ctx, "k_gf_ws_final");
-        if (vec) k_gf_ws_final<true><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw);
-        else k_gf_ws_final<false><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw);
+        if (vec) k_gf_ws_final<true><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw, nb);
+        else k_gf_ws_final<false><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw, nb);
     }
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;

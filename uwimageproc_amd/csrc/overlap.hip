@@ -474,7 +474,12 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
 {
     __shared__ float s_val[29][3];
     __shared__ uint32_t s_words[16];
-    const int f = blockIdx.y, q = blockIdx.x, lane = threadIdx.x;
+    // Workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous range of (frame, keypoint) so that
+    // the raster-ordered keypoints of a frame gather through ONE L2 instead of fetching their patches into all eight.
+    const unsigned total = (unsigned)MAXKP * F, per = (total + 7u) / 8u;
+    const unsigned m = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if (m >= total) return;
+    const int f = m / MAXKP, q = m % MAXKP, lane = threadIdx.x;
     const int n = nkp[f];
     uint8_t *d = desc + ((size_t)f * MAXKP + q) * DESC_BYTES;
     int8_t *bq = bits + ((size_t)f * MAXKP + q) * DESC_K;
@@ -1268,7 +1273,7 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
     }
     {
         uwip_kscope ks(ctx, "k_ov_describe");
-        k_ov_describe<<<dim3(MAXKP, F), 64, 0, ctx->stream>>>(W.Lt, W.Lx, W.Ly, h, w, kps, nkp,
+        k_ov_describe<<<8u * (((unsigned)MAXKP * F + 7u) / 8u), 64, 0, ctx->stream>>>(W.Lt, W.Lx, W.Ly, h, w, kps, nkp,
                                                              ft->d_desc + (size_t)first_slot * MAXKP * DESC_BYTES,
                                                              ft->d_bits + (size_t)first_slot * MAXKP * DESC_K,
                                                              ft->d_pop + (size_t)first_slot * MAXKP, F);
