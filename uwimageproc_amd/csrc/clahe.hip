@@ -858,6 +858,47 @@ UWIP_API int uwip_aclahe_auto(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwi
 // cvtColor(BGR2HSV) / cvtColor(HSV2BGR) for 8-bit images restated from OpenCV 3.4 color.cpp
 // (integer forward tables with hsv_shift = 12; float inverse with hscale = 6/180).  parity unpinned.
 namespace {
+// one pixel: BGR -> (H, S) by the integer forward tables, then HSV -> BGR with the new V
+__device__ __forceinline__ void hsv_replace_px(int b, int g, int r, int vnew, const int *__restrict__ sdiv,
+                                               const int *__restrict__ hdiv, uint32_t &ob8, uint32_t &og8, uint32_t &or8)
+{
+    const int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+    const int diff = v - vmin;
+    const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+    const int sat = (diff * sdiv[v] + (1 << 11)) >> 12;
+    int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+    h = (h * hdiv[diff] + (1 << 11)) >> 12;
+    h += h < 0 ? 180 : 0;
+    // inverse with the new V
+    float hf = (float)(uint8_t)h;
+    const float sf = (float)(uint8_t)sat * (1.f / 255.f), vf = (float)vnew * (1.f / 255.f);
+    float ob, og, orr;
+    if (sf == 0.0f) {
+        ob = og = orr = vf;
+    } else {
+        hf *= (6.f / 180.f);
+        if (hf < 0) do hf += 6; while (hf < 0);
+        else if (hf >= 6) do hf -= 6; while (hf >= 6);
+        int sector = (int)floorf(hf);
+        hf -= (float)sector;
+        if ((unsigned)sector >= 6u) { sector = 0; hf = 0.f; }
+        const float t0 = vf, t1 = vf * (1.f - sf), t2 = vf * (1.f - sf * hf), t3 = vf * (1.f - sf * (1.f - hf));
+        switch (sector) {
+            case 0: ob = t1; og = t3; orr = t0; break;
+            case 1: ob = t1; og = t0; orr = t2; break;
+            case 2: ob = t3; og = t0; orr = t1; break;
+            case 3: ob = t0; og = t2; orr = t1; break;
+            case 4: ob = t0; og = t1; orr = t3; break;
+            default: ob = t2; og = t1; orr = t0; break;
+        }
+    }
+    ob8 = (uint32_t)sat_u8_rne(ob * 255.f);
+    og8 = (uint32_t)sat_u8_rne(og * 255.f);
+    or8 = (uint32_t)sat_u8_rne(orr * 255.f);
+}
+
+// VEC: rows are 4-byte aligned and cols % 4 == 0 -> a thread takes 4 pixels as 3 + 1 dword loads and 3 dword stores
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_hsv_replace_v(const uint8_t *__restrict__ src, size_t sstep, size_t sfs,
                                                       const uint8_t *__restrict__ vnew, size_t vstep, size_t vfs,
                                                       uint8_t *__restrict__ dst, size_t dstep, size_t dfs, int rows,
@@ -867,41 +908,32 @@ __global__ __launch_bounds__(256) void k_hsv_replace_v(const uint8_t *__restrict
     const uint8_t *s = src + (size_t)f * sfs + (size_t)y * sstep;
     const uint8_t *vn = vnew + (size_t)f * vfs + (size_t)y * vstep;
     uint8_t *d = dst + (size_t)f * dfs + (size_t)y * dstep;
-    for (int x = blockIdx.x * 256 + threadIdx.x; x < cols; x += gridDim.x * 256) {
-        const int b = s[3 * x], g = s[3 * x + 1], r = s[3 * x + 2];
-        const int v = max(b, max(g, r)), vmin = min(b, min(g, r));
-        const int diff = v - vmin;
-        const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
-        const int sat = (diff * sdiv[v] + (1 << 11)) >> 12;
-        int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
-        h = (h * hdiv[diff] + (1 << 11)) >> 12;
-        h += h < 0 ? 180 : 0;
-        // inverse with the new V
-        float hf = (float)(uint8_t)h;
-        const float sf = (float)(uint8_t)sat * (1.f / 255.f), vf = (float)vn[x] * (1.f / 255.f);
-        float ob, og, orr;
-        if (sf == 0.0f) {
-            ob = og = orr = vf;
-        } else {
-            hf *= (6.f / 180.f);
-            if (hf < 0) do hf += 6; while (hf < 0);
-            else if (hf >= 6) do hf -= 6; while (hf >= 6);
-            int sector = (int)floorf(hf);
-            hf -= (float)sector;
-            if ((unsigned)sector >= 6u) { sector = 0; hf = 0.f; }
-            const float t0 = vf, t1 = vf * (1.f - sf), t2 = vf * (1.f - sf * hf), t3 = vf * (1.f - sf * (1.f - hf));
-            switch (sector) {
-                case 0: ob = t1; og = t3; orr = t0; break;
-                case 1: ob = t1; og = t0; orr = t2; break;
-                case 2: ob = t3; og = t0; orr = t1; break;
-                case 3: ob = t0; og = t2; orr = t1; break;
-                case 4: ob = t0; og = t1; orr = t3; break;
-                default: ob = t2; og = t1; orr = t0; break;
+    if (VEC) {
+        for (int x4 = blockIdx.x * 256 + threadIdx.x; x4 < cols / 4; x4 += gridDim.x * 256) {
+            const uint32_t *sp = reinterpret_cast<const uint32_t *>(s) + 3 * x4;
+            const uint32_t w[3] = {sp[0], sp[1], sp[2]};
+            const uint32_t vv = reinterpret_cast<const uint32_t *>(vn)[x4];
+            uint32_t o[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 3 * j;
+                const int b = (w[k >> 2] >> ((k & 3) * 8)) & 255, g = (w[(k + 1) >> 2] >> (((k + 1) & 3) * 8)) & 255,
+                          r = (w[(k + 2) >> 2] >> (((k + 2) & 3) * 8)) & 255;
+                uint32_t ob, og, orr;
+                hsv_replace_px(b, g, r, (int)((vv >> (8 * j)) & 255u), sdiv, hdiv, ob, og, orr);
+                o[k >> 2] |= ob << ((k & 3) * 8);
+                o[(k + 1) >> 2] |= og << (((k + 1) & 3) * 8);
+                o[(k + 2) >> 2] |= orr << (((k + 2) & 3) * 8);
             }
+            uint32_t *dp = reinterpret_cast<uint32_t *>(d) + 3 * x4;
+            dp[0] = o[0]; dp[1] = o[1]; dp[2] = o[2];
         }
-        d[3 * x] = (uint8_t)sat_u8_rne(ob * 255.f);
-        d[3 * x + 1] = (uint8_t)sat_u8_rne(og * 255.f);
-        d[3 * x + 2] = (uint8_t)sat_u8_rne(orr * 255.f);
+    } else {
+        for (int x = blockIdx.x * 256 + threadIdx.x; x < cols; x += gridDim.x * 256) {
+            uint32_t ob, og, orr;
+            hsv_replace_px(s[3 * x], s[3 * x + 1], s[3 * x + 2], vn[x], sdiv, hdiv, ob, og, orr);
+            d[3 * x] = (uint8_t)ob; d[3 * x + 1] = (uint8_t)og; d[3 * x + 2] = (uint8_t)orr;
+        }
     }
 }
 
@@ -933,9 +965,17 @@ UWIP_API int uwip_hsv_replace_v(uwip_ctx *ctx, const uwip_batch_u8 *bgr, const u
     const int *tabs = hsv_tables(ctx);
     if (!tabs) return UWIP_ERR_NOMEM;
     uwip_kscope ks(ctx, "k_hsv_replace_v");
-    k_hsv_replace_v<<<dim3(uwip_cdiv(bgr->cols, 256 * 2), (unsigned)bgr->rows, (unsigned)bgr->frames), 256, 0, ctx->stream>>>(
-        (const uint8_t *)bgr->data, bgr->step, bgr->frame_stride, (const uint8_t *)v_new->data, v_new->step, v_new->frame_stride,
-        (uint8_t *)bgr_out->data, bgr_out->step, bgr_out->frame_stride, bgr->rows, bgr->cols, tabs, tabs + 256);
+    auto al4 = [](const uwip_batch_u8 *b) { return ((uintptr_t)b->data | b->step | b->frame_stride) % 4 == 0; };
+    const bool vec = bgr->cols % 4 == 0 && al4(bgr) && al4(v_new) && al4(bgr_out);
+    const dim3 grid(uwip_cdiv(vec ? bgr->cols / 4 : bgr->cols, 256), (unsigned)bgr->rows, (unsigned)bgr->frames);
+    if (vec)
+        k_hsv_replace_v<true><<<grid, 256, 0, ctx->stream>>>(
+            (const uint8_t *)bgr->data, bgr->step, bgr->frame_stride, (const uint8_t *)v_new->data, v_new->step, v_new->frame_stride,
+            (uint8_t *)bgr_out->data, bgr_out->step, bgr_out->frame_stride, bgr->rows, bgr->cols, tabs, tabs + 256);
+    else
+        k_hsv_replace_v<false><<<grid, 256, 0, ctx->stream>>>(
+            (const uint8_t *)bgr->data, bgr->step, bgr->frame_stride, (const uint8_t *)v_new->data, v_new->step, v_new->frame_stride,
+            (uint8_t *)bgr_out->data, bgr_out->step, bgr_out->frame_stride, bgr->rows, bgr->cols, tabs, tabs + 256);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }

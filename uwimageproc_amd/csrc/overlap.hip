@@ -155,14 +155,13 @@ __global__ __launch_bounds__(256) void k_ov_kc(const float *__restrict__ Lsm, in
         uint32_t b = __float_as_uint(m);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
-        // one atomic per block, and only when it can raise the running maximum (max is exact: order-free)
+        // one partial per block, reduced by k_ov_kc_max (hundreds of blocks polling one word of a frame serialise
+        // on a single L2 channel; max is exact whatever the order)
         __shared__ uint32_t s_mx[4];
         if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = b;
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const uint32_t m4 = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
-            if (m4 > __hip_atomic_load(&hmax_bits[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&hmax_bits[f], m4);
-        }
+        if (threadIdx.x == 0)
+            hist[((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
     } else {
         const float hmax = __uint_as_float(hmax_bits[f]);
         if (in && m != 0.0f && hmax != 0.0f) {
@@ -175,6 +174,19 @@ __global__ __launch_bounds__(256) void k_ov_kc(const float *__restrict__ Lsm, in
         for (int i = threadIdx.x; i < 301; i += 256)
             if (s_hist[i]) atomicAdd(&hist[(size_t)f * 304 + i], s_hist[i]);
     }
+}
+
+__global__ __launch_bounds__(256) void k_ov_kc_max(const uint32_t *__restrict__ part, int nb, uint32_t *__restrict__ hmax_bits)
+{
+    __shared__ uint32_t s_mx[4];
+    const int f = blockIdx.x;
+    uint32_t b = 0;
+    for (int i = threadIdx.x; i < nb; i += 256) b = max(b, part[(size_t)f * nb + i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x == 0) hmax_bits[f] = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
 }
 
 __global__ void k_ov_kc_final(const uint32_t *__restrict__ hmax_bits, const uint32_t *__restrict__ hist, float *__restrict__ kc, int F)
@@ -1226,9 +1238,12 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
             k_ov_conv<true><<<g, 256, 0, ctx->stream>>>(Lt, W.tmp, h, w, K1);
             k_ov_conv<false><<<g, 256, 0, ctx->stream>>>(W.tmp, W.Lsm, h, w, K1);
             if (lv == 0) {
-                UWIP_HIP(ctx, hipMemsetAsync(W.hmax, 0, sizeof(uint32_t) * F, ctx->stream));
+                const int nbk = (int)(g.x * g.y);
+                uint32_t *kpart = (uint32_t *)uwip_ws(ctx, "ov.kcpart", sizeof(uint32_t) * nbk * F);
+                if (!kpart) return UWIP_ERR_NOMEM;
+                k_ov_kc<0><<<g, 256, 0, ctx->stream>>>(W.Lsm, h, w, W.hmax, kpart);
+                k_ov_kc_max<<<F, 256, 0, ctx->stream>>>(kpart, nbk, W.hmax);
                 UWIP_HIP(ctx, hipMemsetAsync(W.khist, 0, sizeof(uint32_t) * 304 * F, ctx->stream));
-                k_ov_kc<0><<<g, 256, 0, ctx->stream>>>(W.Lsm, h, w, W.hmax, W.khist);
                 k_ov_kc<1><<<g, 256, 0, ctx->stream>>>(W.Lsm, h, w, W.hmax, W.khist);
                 k_ov_kc_final<<<uwip_cdiv(F, 64), 64, 0, ctx->stream>>>(W.hmax, W.khist, W.kc, F);
             }
