@@ -351,21 +351,29 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
         const int tx1 = max(ci.cx - 1, 0), tx2 = min(ci.cx, gx - 1);
         const int ty1 = max(ci.cy - 1, 0), ty2 = min(ci.cy, gy - 1);
         __syncthreads();
-        for (int idx = tid; idx < SWEEP_GROUP * 256; idx += SWEEP_THREADS) {
-            const int c = idx >> 8, v = idx & 255;
-            const uint8_t *Lc = L + (size_t)c * tiles * 256;
-            const uint32_t a = Lc[((size_t)ty1 * gx + tx1) * 256 + v];
-            const uint32_t b = Lc[((size_t)ty1 * gx + tx2) * 256 + v];
-            const uint32_t cc = Lc[((size_t)ty2 * gx + tx1) * 256 + v];
-            const uint32_t d = Lc[((size_t)ty2 * gx + tx2) * 256 + v];
-            s_pack[idx] = a | (b << 8) | (cc << 16) | (d << 24);
+        // four grey levels per thread: one dword from each of the four tiles' LUTs, byte-transposed by v_perm into
+        // four packed entries (TL | TR << 8 | BL << 16 | BR << 24) and stored as one 16-byte LDS write
+        for (int idx = tid; idx < SWEEP_GROUP * 64; idx += SWEEP_THREADS) {
+            const int c = idx >> 6, v4 = idx & 63;
+            const uint32_t *Lc = reinterpret_cast<const uint32_t *>(L + (size_t)c * tiles * 256);
+            const uint32_t a = Lc[((size_t)ty1 * gx + tx1) * 64 + v4];
+            const uint32_t b = Lc[((size_t)ty1 * gx + tx2) * 64 + v4];
+            const uint32_t cc = Lc[((size_t)ty2 * gx + tx1) * 64 + v4];
+            const uint32_t d = Lc[((size_t)ty2 * gx + tx2) * 64 + v4];
+            const uint32_t t0 = __builtin_amdgcn_perm(b, a, 0x05010400u), t1 = __builtin_amdgcn_perm(b, a, 0x07030602u);
+            const uint32_t u0 = __builtin_amdgcn_perm(d, cc, 0x05010400u), u1 = __builtin_amdgcn_perm(d, cc, 0x07030602u);
+            reinterpret_cast<uint4 *>(s_pack)[idx] =
+                make_uint4(__builtin_amdgcn_perm(u0, t0, 0x05040100u), __builtin_amdgcn_perm(u0, t0, 0x07060302u),
+                           __builtin_amdgcn_perm(u1, t1, 0x05040100u), __builtin_amdgcn_perm(u1, t1, 0x07060302u));
         }
         if (tid < SWEEP_GROUP) s_diff[tid] = tid == 0 ? 1u : 0u;
         __syncthreads();
         // a clip limit above the tallest bin of all four tiles leaves their LUTs unchanged: when clip limit c has
         // byte-identical packed LUTs to c-1 in this cell, every pixel's output repeats and need not be recomputed
-        for (int idx = tid + 256; idx < SWEEP_GROUP * 256; idx += SWEEP_THREADS)
-            if (s_pack[idx] != s_pack[idx - 256]) s_diff[idx >> 8] = 1u;
+        for (int idx = tid + 64; idx < SWEEP_GROUP * 64; idx += SWEEP_THREADS) {
+            const uint4 p = reinterpret_cast<const uint4 *>(s_pack)[idx], q = reinterpret_cast<const uint4 *>(s_pack)[idx - 64];
+            if (((p.x ^ q.x) | (p.y ^ q.y) | (p.z ^ q.z) | (p.w ^ q.w)) != 0u) s_diff[idx >> 6] = 1u;
+        }
         __syncthreads();
         uint32_t diffmask = 0;
 #pragma unroll
