@@ -317,12 +317,14 @@ struct CellItem {
 };
 
 // Same-bin LDS atomics from one wave serialise, and neighbouring pixels of a smooth underwater frame land in
-// few bins: the output histograms are therefore replicated SWEEP_REP times, keyed by the low lane bits, and
-// a block is 1024 threads (16 waves share one set of packed LUTs + replicas: 85 KB of LDS, one block per CU).
+// few bins: the output histograms are therefore replicated SWEEP_REP times, keyed by the thread index modulo
+// SWEEP_REP.  A block is 512 threads; packed LUTs (17 KB) + 3 replicas of 16-bit counters (27 KB) = 45 KB of LDS,
+// three blocks per CU (measured: 2 replicas x 4 blocks and 4 replicas x 2 blocks are both slower).
 constexpr int SWEEP_THREADS = 512;
-constexpr int SWEEP_REP = 2;
+constexpr int SWEEP_REP = 3;
+constexpr int SWEEP_HROWS = (SWEEP_GROUP + 1) / 2;   // two clip limits share a word: 16-bit counters (a block sees < 65536 pixels)
 constexpr int SWEEP_SPREAD = 8;    // multiple of SWEEP_THREADS / 64
-constexpr int SWEEP_RSTRIDE = SWEEP_GROUP * 256 + 8;   // +8 words: equal bins of different replicas fall in different LDS banks
+constexpr int SWEEP_RSTRIDE = SWEEP_HROWS * 256 + 8;   // +8 words: equal bins of different replicas fall in different LDS banks
 __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__restrict__ src, size_t step,
                                                      size_t fstride, int gx, int gy, float inv_tw,
                                                      float inv_th,
@@ -334,13 +336,13 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_sweep[];
     uint32_t *s_pack = s_sweep;                                   // [SWEEP_GROUP][256]
-    uint32_t *s_hist = s_sweep + SWEEP_GROUP * 256;               // [SWEEP_REP][SWEEP_GROUP][256]
+    uint32_t *s_hist = s_sweep + SWEEP_GROUP * 256;               // [SWEEP_REP][SWEEP_HROWS][256], two 16-bit counters per word
     __shared__ uint32_t s_diff[SWEEP_GROUP];
     const int tid = threadIdx.x;
     const int cg = blockIdx.y, f = blockIdx.z;
     const int tiles = gx * gy;
     for (int i = tid; i < SWEEP_REP * SWEEP_RSTRIDE; i += SWEEP_THREADS) s_hist[i] = 0;
-    uint32_t *my_hist = s_hist + (tid & (SWEEP_REP - 1)) * SWEEP_RSTRIDE;
+    uint32_t *my_hist = s_hist + (tid % SWEEP_REP) * SWEEP_RSTRIDE;
     const uint8_t *fb = src + (size_t)f * fstride;
     const uint8_t *L = luts + ((size_t)f * SWEEP_NCL + (size_t)cg * SWEEP_GROUP) * tiles * 256;
     const int i0 = blockIdx.x * items_per_block, i1 = min(nitems, i0 + items_per_block);
@@ -422,7 +424,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
                     const f32x2 ac = {(float)(pk[c] & 255u), (float)((pk[c] >> 16) & 255u)};
                     const f32x2 bd = {(float)((pk[c] >> 8) & 255u), (float)(pk[c] >> 24)};
                     const f32x2 t = (ac * xa1v + bd * xav) * yv;
-                    atomicAdd(&my_hist[c * 256 + __builtin_amdgcn_cvt_pk_u8_f32(t.x + t.y, 0, 0u)], 1u);
+                    atomicAdd(&my_hist[(c >> 1) * 256 + __builtin_amdgcn_cvt_pk_u8_f32(t.x + t.y, 0, 0u)], (c & 1) ? 65536u : 1u);
                 }
                 continue;
             }
@@ -439,7 +441,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
                 } else if (single) {
                     continue;                        // one cell per block: the repeated histogram is copied at flush time
                 }
-                atomicAdd(&my_hist[c * 256 + o], 1u);
+                atomicAdd(&my_hist[(c >> 1) * 256 + o], (c & 1) ? 65536u : 1u);
             }
         }
     }
@@ -454,8 +456,9 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
             src = ((31 - __builtin_clz(m | 1u)) << 8) | (i & 255);
         }
         uint32_t sum = 0;
+        const int word = ((src >> 9) << 8) | (src & 255), sh = ((src >> 8) & 1) * 16;
 #pragma unroll
-        for (int r = 0; r < SWEEP_REP; ++r) sum += s_hist[r * SWEEP_RSTRIDE + src];
+        for (int r = 0; r < SWEEP_REP; ++r) sum += (s_hist[r * SWEEP_RSTRIDE + word] >> sh) & 0xffffu;
         if (sum) atomicAdd(&out[i], sum);
     }
 }
@@ -783,7 +786,7 @@ UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int resi
         const CellItem *d_items = (const CellItem *)d_tab;
         const int nitems = (int)(bytes / sizeof(CellItem));
         const int cell_px = std::max(1, g.tw * g.th);
-        const int ipb = std::max(1, std::min(32, 32768 / cell_px));
+        const int ipb = std::max(1, std::min(32, 32768 / cell_px));   // <= 32768 pixels per block: the 16-bit LDS counters cannot overflow
         dim3 grid(uwip_cdiv(nitems, ipb), SWEEP_NCL / SWEEP_GROUP, (unsigned)F);
         uwip_kscope ks(ctx, "k_clahe_sweep");
         const size_t sweep_lds = sizeof(uint32_t) * ((size_t)SWEEP_GROUP * 256 + (size_t)SWEEP_REP * SWEEP_RSTRIDE);
