@@ -141,10 +141,16 @@ __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restric
     for (int j = j0 + wave; j < j1; j += 4) {
         const int y = reflect101(ty * th + j, rows);
         const uint8_t *row = base + (size_t)y * step;
-        for (int i = lane; i < tw; i += 64) {
-            int x = tx * tw + i;
-            if (x >= cols) x = reflect101(x, cols);
-            atomicAdd(&my[row[x]], 1u);
+        // lane l takes pixels l*K .. l*K+K-1 (K = ceil(tw/64)): the 64 pixels of one LDS atomic are K apart, so fewer of
+        // them hit the same bin than 64 neighbours of a smooth frame would
+        const int K = (tw + 63) >> 6;
+        for (int k = 0; k < K; ++k) {
+            const int i = lane * K + k;
+            if (i < tw) {
+                int x = tx * tw + i;
+                if (x >= cols) x = reflect101(x, cols);
+                atomicAdd(&my[row[x]], 1u);
+            }
         }
     }
     __syncthreads();
