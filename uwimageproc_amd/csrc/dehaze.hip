@@ -597,20 +597,22 @@ int run_bglight(uwip_ctx *ctx, const uwip_batch_u8 *in, int w, DzBufs &b, const 
     const int F = in->frames, H = in->rows, W = in->cols;
     const uint8_t *img = (const uint8_t *)in->data;
     k_dz_init_scalars<<<uwip_cdiv(F, 64), 64, 0, ctx->stream>>>(b.si, F);
-    {
+    const bool fast15 = uwip_winfilter15_ok(img, in->step, in->frame_stride, H, W, w);
+    static_assert(SI_MN == 0 && SI_MX == 1 && SI_RMN == 2 && SI_RMX == 3, "k_winfilter15 writes the four scalars in this order");
+    if (!(fast15 && also_min)) {   // otherwise k_winfilter15 gathers the frame min / max while it filters
         uwip_kscope ks(ctx, "k_dz_minmax");
         k_dz_minmax<<<dim3(RED_BLOCKS, F), 256, 0, ctx->stream>>>(img, in->step, in->frame_stride, H, W, b.si);
     }
     const int pad = w / 2;
     b.u8min = nullptr;
-    if (uwip_winfilter15_ok(img, in->step, in->frame_stride, H, W, w)) {
+    if (fast15) {
         // one pass for the window maximum and (when the transmission follows) the window minimum
         uint8_t *mn = nullptr;
         if (also_min) {
             mn = (uint8_t *)uwip_ws(ctx, "dz.u8min", (size_t)3 * H * W * F);
             if (!mn) return UWIP_ERR_NOMEM;
         }
-        const int rc = uwip_winfilter15(ctx, img, in->step, in->frame_stride, F, H, W, b.u8planes, mn);
+        const int rc = uwip_winfilter15(ctx, img, in->step, in->frame_stride, F, H, W, b.u8planes, mn, mn ? b.si : nullptr, SI_COUNT);
         if (rc) return rc;
         b.u8min = mn;
     } else {

@@ -60,8 +60,10 @@ const void *uwip_table_put(uwip_ctx *ctx, const std::string &key, const void *ho
 int uwip_prof_flush(uwip_ctx *ctx);
 // winfilter15.hip: 15x15 window max and/or min of interleaved 3-channel u8 frames -> planar [F][3][H][W]
 bool uwip_winfilter15_ok(const uint8_t *img, size_t step, size_t fs, int H, int W, int w);
+// stats (optional, both filters only): stats[f*stride + {0..3}] = min, max of all channels, min, max of channel 2,
+// by atomicMin / atomicMax onto the caller's 255 / 0 initial values
 int uwip_winfilter15(uwip_ctx *ctx, const uint8_t *img, size_t step, size_t fs, int F, int H, int W, uint8_t *out_max,
-                     uint8_t *out_min);
+                     uint8_t *out_min, int *stats = nullptr, int stats_stride = 0);
 // guided_filter_ws.hip: the wave-strip guided filter (guide u8 x3, P [F][np][H][W] -> Q, AB [F*np][4][H][W] scratch)
 int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs, const int *gnorm, int gstride,
                        const double *P, double *Q, double *AB, int F, int np, int H, int W, int r, double eps);

@@ -118,10 +118,15 @@ struct VState {
     }
 };
 
+// stats (optional, needs both filters): stats[f * stats_stride + {0,1,2,3}] = min, max over all channels and min, max of
+// the red channel (bgdehaze D0), by atomicMin / atomicMax -- the caller initialises them to 255 / 0.
 template <bool DO_MAX, bool DO_MIN>
 __global__ __launch_bounds__(64) void k_winfilter15(const uint8_t *__restrict__ img, size_t step, size_t fs, int H, int W,
-                                                    uint8_t *__restrict__ out_max, uint8_t *__restrict__ out_min, int rpc)
+                                                    uint8_t *__restrict__ out_max, uint8_t *__restrict__ out_min, int rpc,
+                                                    int *__restrict__ stats, int stats_stride)
 {
+    constexpr bool BOTH = DO_MAX && DO_MIN;
+    uint32_t st_max = 0, st_imax = 0, st_rmax = 0, st_rimax = 0;
     const int l = threadIdx.x, f = blockIdx.z;
     const int col0 = (int)blockIdx.x * WF15_TS - 8 + 4 * l;      // image column of the lane's first sample
     const bool in = col0 >= 0 && col0 < W;                         // W % 4 == 0: all four or none
@@ -165,6 +170,12 @@ __global__ __launch_bounds__(64) void k_winfilter15(const uint8_t *__restrict__ 
             const uint32_t xr = rowin ? xorv : 0u;
 #pragma unroll
             for (int k = 0; k < 6; ++k) ui.v[k] = u.v[k] ^ xr;     // 255 - v inside the image, 0 outside
+            if (BOTH) {
+                const uint32_t r = pkmax(u.v[4], u.v[5]), ri = pkmax(ui.v[4], ui.v[5]);
+                st_rmax = pkmax(st_rmax, r); st_rimax = pkmax(st_rimax, ri);
+                st_max = pkmax(st_max, pkmax(pkmax(pkmax(u.v[0], u.v[1]), pkmax(u.v[2], u.v[3])), r));
+                st_imax = pkmax(st_imax, pkmax(pkmax(pkmax(ui.v[0], ui.v[1]), pkmax(ui.v[2], ui.v[3])), ri));
+            }
             const P3 o = smin.push(hmax15(ui));
             if (Y >= y0 && outl) {
 #pragma unroll
@@ -188,6 +199,19 @@ __global__ __launch_bounds__(64) void k_winfilter15(const uint8_t *__restrict__ 
 #pragma unroll
         for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
     }
+    if (BOTH && stats) {
+        int a = (int)max(st_max & 0xffffu, st_max >> 16), b = (int)max(st_imax & 0xffffu, st_imax >> 16);
+        int c = (int)max(st_rmax & 0xffffu, st_rmax >> 16), d = (int)max(st_rimax & 0xffffu, st_rimax >> 16);
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            a = max(a, __shfl_xor(a, sft, 64)); b = max(b, __shfl_xor(b, sft, 64));
+            c = max(c, __shfl_xor(c, sft, 64)); d = max(d, __shfl_xor(d, sft, 64));
+        }
+        if (l == 0) {
+            int *sp = stats + (size_t)f * stats_stride;
+            atomicMin(&sp[0], 255 - b); atomicMax(&sp[1], a); atomicMin(&sp[2], 255 - d); atomicMax(&sp[3], c);
+        }
+    }
 }
 
 }  // namespace
@@ -199,8 +223,9 @@ bool uwip_winfilter15_ok(const uint8_t *img, size_t step, size_t fs, int H, int 
 
 // out_max / out_min: planar [F][3][H][W] (either may be null)
 int uwip_winfilter15(uwip_ctx *ctx, const uint8_t *img, size_t step, size_t fs, int F, int H, int W, uint8_t *out_max,
-                     uint8_t *out_min)
+                     uint8_t *out_min, int *stats, int stats_stride)
 {
+    UWIP_REQUIRE(ctx, !stats || (out_max && out_min), "the fused statistics need both filters");
     UWIP_REQUIRE(ctx, uwip_winfilter15_ok(img, step, fs, H, W, 15), "k_winfilter15: unsupported geometry");
     UWIP_REQUIRE(ctx, out_max || out_min, "no output");
     UWIP_REQUIRE(ctx, (((uintptr_t)out_max | (uintptr_t)out_min) & 3) == 0, "unaligned output planes");
@@ -211,9 +236,9 @@ int uwip_winfilter15(uwip_ctx *ctx, const uint8_t *img, size_t step, size_t fs, 
     const int rpc = (H + chunks - 1) / chunks;
     const dim3 grid(strips, uwip_cdiv(H, rpc), (unsigned)F);
     uwip_kscope ks(ctx, "k_winfilter15");
-    if (out_max && out_min) k_winfilter15<true, true><<<grid, 64, 0, ctx->stream>>>(img, step, fs, H, W, out_max, out_min, rpc);
-    else if (out_max) k_winfilter15<true, false><<<grid, 64, 0, ctx->stream>>>(img, step, fs, H, W, out_max, out_min, rpc);
-    else k_winfilter15<false, true><<<grid, 64, 0, ctx->stream>>>(img, step, fs, H, W, out_max, out_min, rpc);
+    if (out_max && out_min) k_winfilter15<true, true><<<grid, 64, 0, ctx->stream>>>(img, step, fs, H, W, out_max, out_min, rpc, stats, stats_stride);
+    else if (out_max) k_winfilter15<true, false><<<grid, 64, 0, ctx->stream>>>(img, step, fs, H, W, out_max, out_min, rpc, nullptr, 0);
+    else k_winfilter15<false, true><<<grid, 64, 0, ctx->stream>>>(img, step, fs, H, W, out_max, out_min, rpc, nullptr, 0);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
