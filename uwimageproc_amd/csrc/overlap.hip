@@ -486,6 +486,7 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
 {
     __shared__ float s_val[29][3];
     __shared__ uint32_t s_words[16];
+    __shared__ float s_patch[3][21][22];   // [plane][x offset][y offset], padded
     // Workgroups are dealt round-robin over the 8 XCDs: give every XCD a contiguous range of (frame, keypoint) so that
     // the raster-ordered keypoints of a frame gather through ONE L2 instead of fetching their patches into all eight.
     const unsigned total = (unsigned)MAXKP * F, per = (total + 7u) / 8u;
@@ -509,6 +510,18 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
     const float *Y = Ly + ((size_t)kp.level * F + f) * npx;
     const float sc = (float)D_SSIZE[kp.level];
     if (lane < 16) s_words[lane] = 0;
+    // The three grids (2x2 cells of 10, 3x3 of 7, 4x4 of 5 samples a side) draw from one 21 x 21 lattice of sample
+    // positions (offsets -10..10 times the scale): all 64 lanes fetch it once into LDS, x fastest so that a wave's
+    // loads run along image rows, and the cells then sum from LDS in the oracle's order.
+    for (int idx = lane; idx < 21 * 21; idx += 64) {
+        const int l = idx / 21, kk = idx - l * 21;       // l: y offset index, kk: x offset index
+        const float sy = kp.y + (float)(l - 10) * sc, sx = kp.x + (float)(kk - 10) * sc;
+        const int y1 = min(max((int)floorf(sy + 0.5f), 0), h - 1);
+        const int x1 = min(max((int)floorf(sx + 0.5f), 0), w - 1);
+        const size_t o = (size_t)y1 * w + x1;
+        s_patch[0][kk][l] = T[o]; s_patch[1][kk][l] = X[o]; s_patch[2][kk][l] = Y[o];
+    }
+    __syncthreads();
     if (lane < 29) {
         int z, ci;
         if (lane < 4) { z = 0; ci = lane; } else if (lane < 13) { z = 1; ci = lane - 4; } else { z = 2; ci = lane - 13; }
@@ -518,12 +531,9 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
         int ns = 0;
         for (int kk = i0; kk < i0 + st; ++kk)
             for (int l = j0; l < j0 + st; ++l) {
-                const float sy = kp.y + (float)l * sc, sx = kp.x + (float)kk * sc;
-                const int y1 = min(max((int)floorf(sy + 0.5f), 0), h - 1);
-                const int x1 = min(max((int)floorf(sx + 0.5f), 0), w - 1);
-                di = di + T[(size_t)y1 * w + x1];
-                dx = dx + X[(size_t)y1 * w + x1];
-                dy = dy + Y[(size_t)y1 * w + x1];
+                di = di + s_patch[0][kk + 10][l + 10];
+                dx = dx + s_patch[1][kk + 10][l + 10];
+                dy = dy + s_patch[2][kk + 10][l + 10];
                 ns++;
             }
         s_val[lane][0] = di / (float)ns; s_val[lane][1] = dx / (float)ns; s_val[lane][2] = dy / (float)ns;
