@@ -320,8 +320,9 @@ __global__ void k_recover_final(const double *__restrict__ part, int nb, double 
     s[SC_JMIN0] = a; s[SC_JMAX0] = b; s[SC_JMIN1] = c; s[SC_JMAX1] = d; s[SC_MEANR] = e / npix;
 }
 
-// normalise J in place, partial sums for the means (BGDehaze.py:54,56,61)
-__global__ __launch_bounds__(256) void k_normJ(double *__restrict__ Q, const double *__restrict__ sc, int H, int W,
+// partial sums for the means of the min-max normalised J (BGDehaze.py:54,56,61).  J stays as it is in Q: every consumer
+// applies (J - min) / (max - min) itself (restored_px), which saves rewriting two float64 planes.
+__global__ __launch_bounds__(256) void k_normJ(const double *__restrict__ Q, const double *__restrict__ sc, int H, int W,
                                                double *__restrict__ part /*[F][nb][2]*/)
 {
     __shared__ double scratch[4];
@@ -329,11 +330,10 @@ __global__ __launch_bounds__(256) void k_normJ(double *__restrict__ Q, const dou
     const size_t n = (size_t)H * W;
     const double *s = sc + (size_t)f * SC_COUNT;
     const double a0 = s[SC_JMIN0], d0 = s[SC_JMAX0] - s[SC_JMIN0], a1 = s[SC_JMIN1], d1 = s[SC_JMAX1] - s[SC_JMIN1];
-    double *q0 = Q + (size_t)f * 2 * n, *q1 = q0 + n;
+    const double *q0 = Q + (size_t)f * 2 * n, *q1 = q0 + n;
     double s0 = 0.0, s1 = 0.0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const double v0 = (q0[i] - a0) / d0, v1 = (q1[i] - a1) / d1;
-        q0[i] = v0; q1[i] = v1;
         s0 += v0; s1 += v1;
     }
     const double r0 = block_reduce_f64(s0, 0, scratch), r1 = block_reduce_f64(s1, 0, scratch);
@@ -366,8 +366,8 @@ __global__ void k_normJ_final(const double *__restrict__ part, int nb, const int
 __device__ __forceinline__ void restored_px(const uint8_t *p, const double *nJ0, const double *nJ1, size_t i,
                                             const double *s, int mn, int mx, double out[3])
 {
-    out[0] = nJ0[i];
-    out[1] = nJ1[i];
+    out[0] = (nJ0[i] - s[SC_JMIN0]) / (s[SC_JMAX0] - s[SC_JMIN0]);   // min-max normalised J (BGDehaze.py:54,56)
+    out[1] = (nJ1[i] - s[SC_JMIN1]) / (s[SC_JMAX1] - s[SC_JMIN1]);
     const double rrec = normv(p[2], mn, mx) * s[SC_COEFF];
     out[2] = (rrec - s[SC_RMIN]) / (s[SC_RMAX] - s[SC_RMIN]);
 }
