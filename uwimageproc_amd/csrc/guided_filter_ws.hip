@@ -159,18 +159,24 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
         }
     }
 
-    auto load_row = [&](int yy, SolveRow<NP> &R) {
+    // A row buffer is cleared ONCE (guide bytes = mn, p = 0: contributes nothing); load_row then only overwrites the
+    // lanes / columns that are inside the image, so out-of-image columns stay neutral without a per-row refill.
+    auto clear_row = [&](SolveRow<NP> &R) {
         R.g[0] = R.g[1] = R.g[2] = fillw;
 #pragma unroll
         for (int ip = 0; ip < NP; ++ip) R.p[ip][0] = R.p[ip][1] = R.p[ip][2] = R.p[ip][3] = 0.0;
-        if (yy < 0) return;
+    };
+    // per-lane bases; the row offsets below are wave-uniform (scalar) products
+    const uint8_t *g_lane = gf + (size_t)(sg.in[0] ? sg.x0 : 0) * 3;
+    const double *p_lane = pin + (sg.in[0] ? sg.x0 : 0);
+    auto load_row = [&](int yy, SolveRow<NP> &R) {   // yy must be a row of the image
         if (VEC) {
             if (sg.in[0]) {
-                const uint32_t *q = reinterpret_cast<const uint32_t *>(gf + (size_t)yy * step + (size_t)sg.x0 * 3);
+                const uint32_t *q = reinterpret_cast<const uint32_t *>(g_lane + (size_t)yy * step);
                 R.g[0] = q[0]; R.g[1] = q[1]; R.g[2] = q[2];
 #pragma unroll
                 for (int ip = 0; ip < NP; ++ip) {
-                    const double2 *pp = reinterpret_cast<const double2 *>(pin + (size_t)ip * n + (size_t)yy * W + sg.x0);
+                    const double2 *pp = reinterpret_cast<const double2 *>(p_lane + ((size_t)ip * H + yy) * W);
                     const double2 u = pp[0], v = pp[1];
                     R.p[ip][0] = u.x; R.p[ip][1] = u.y; R.p[ip][2] = v.x; R.p[ip][3] = v.y;
                 }
@@ -196,7 +202,9 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
         for (int j = 0; j < 4; ++j) {
             const uint32_t a = (uint32_t)max(byte_of(R.g, 3 * j) - mn, 0), b = (uint32_t)max(byte_of(R.g, 3 * j + 1) - mn, 0),
                            c = (uint32_t)max(byte_of(R.g, 3 * j + 2) - mn, 0);
-            const uint32_t v[9] = {a, b, c, a * a, a * b, a * c, b * b, b * c, c * c};
+            // a, b, c < 256: v_mul_u32_u24 (full rate) instead of the quarter-rate 32-bit multiply
+            const uint32_t v[9] = {a, b, c, (uint32_t)__umul24(a, a), (uint32_t)__umul24(a, b), (uint32_t)__umul24(a, c),
+                                   (uint32_t)__umul24(b, b), (uint32_t)__umul24(b, c), (uint32_t)__umul24(c, c)};
 #pragma unroll
             for (int k = 0; k < 9; ++k) gi[j][k] = ADD ? gi[j][k] + v[k] : gi[j][k] - v[k];
             const double da = (double)a, db = (double)b, dc = (double)c;
@@ -215,23 +223,29 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
     // warm-up: rows [max(0, y0 - r), y0 + r) in batches of four loads
     int v = max(y0 - r, 0);
     const int wend = min(y0 + r, H);   // first row that belongs to the steady loop
-    for (; v < wend; v += 4) {
+    {
         SolveRow<NP> R0, R1, R2, R3;
-        load_row(v, R0);
-        load_row(v + 1 < wend ? v + 1 : -1, R1);
-        load_row(v + 2 < wend ? v + 2 : -1, R2);
-        load_row(v + 3 < wend ? v + 3 : -1, R3);
-        accum(R0, ADD); accum(R1, ADD); accum(R2, ADD); accum(R3, ADD);
+        clear_row(R0); clear_row(R1); clear_row(R2); clear_row(R3);
+        for (; v < wend; v += 4) {
+            load_row(v, R0);
+            if (v + 1 < wend) load_row(v + 1, R1);
+            if (v + 2 < wend) load_row(v + 2, R2);
+            if (v + 3 < wend) load_row(v + 3, R3);
+            accum(R0, ADD);
+            if (v + 1 < wend) accum(R1, ADD);
+            if (v + 2 < wend) accum(R2, ADD);
+            if (v + 3 < wend) accum(R3, ADD);
+        }
     }
     SolveRow<NP> Ra, Rs;
-    load_row(y0 + r < H ? y0 + r : -1, Ra);
-    load_row(-1, Rs);
+    clear_row(Ra); clear_row(Rs);
+    if (y0 + r < H) load_row(y0 + r, Ra);
     for (int y = y0; y < y1; ++y) {
-        // rows [y - r, y + r]: add y + r, drop y - r - 1 (only rows this block added itself)
-        accum(Ra, ADD);
+        // rows [y - r, y + r]: add y + r, drop y - r - 1 (only rows this block added itself); all conditions uniform
+        if (y + r < H) accum(Ra, ADD);
         if (y > y0 && y - r - 1 >= 0) accum(Rs, SUB);
-        load_row(y + 1 + r < H ? y + 1 + r : -1, Ra);
-        load_row((y + 1 > y0 && y - r >= 0) ? y - r : -1, Rs);
+        if (y + 1 + r < H) load_row(y + 1 + r, Ra);
+        if (y - r >= 0) load_row(y - r, Rs);
 
         // ---- horizontal prefix of the nine guide planes
         {
@@ -367,15 +381,18 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
     int s = by * spw, y = s;
     if (s >= s_end) return;
 
-    auto load_row = [&](int yy, FinalRow &R) {
+    // row buffers are zeroed once; load_row only overwrites in-image columns (yy must be a row of the image)
+    auto clear_row = [&](FinalRow &R) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) R.v[k][0] = R.v[k][1] = R.v[k][2] = R.v[k][3] = 0.0;
-        if (yy < 0) return;
+    };
+    const double *s_lane = sp + (sg.in[0] ? sg.x0 : 0);
+    auto load_row = [&](int yy, FinalRow &R) {
         if (VEC) {
             if (sg.in[0]) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const double2 *pp = reinterpret_cast<const double2 *>(sp + (size_t)k * n + (size_t)yy * W + sg.x0);
+                    const double2 *pp = reinterpret_cast<const double2 *>(s_lane + ((size_t)k * H + yy) * W);
                     const double2 u = pp[0], v = pp[1];
                     R.v[k][0] = u.x; R.v[k][1] = u.y; R.v[k][2] = v.x; R.v[k][3] = v.y;
                 }
@@ -401,6 +418,7 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
             for (int j = 0; j < 4; ++j) d[k][j] = cur.v[k][j] - prev.v[k][j];
         if (lo >= 0 && hi / rpc != lo / rpc) {   // uniform: the window straddles a chunk start of S
             FinalRow E;
+            clear_row(E);
             load_row((hi / rpc) * rpc - 1, E);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
@@ -414,7 +432,10 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
         const bool more = sn < s_end;
         if (more) {
             load_row(min(yn + r, H - 1), prev);                    // next cur
-            if (chain_start) load_row(yn - r - 1, cur);            // next prev (else: this cur)
+            if (chain_start) {                                     // next prev (else: this cur)
+                if (yn - r - 1 >= 0) load_row(yn - r - 1, cur);
+                else clear_row(cur);
+            }
         }
         uint32_t gw[3] = {0u, 0u, 0u};
         if (VEC) {
@@ -477,7 +498,8 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
     };
 
     FinalRow A, B;
-    load_row(y - r - 1, A);
+    clear_row(A); clear_row(B);
+    if (y - r - 1 >= 0) load_row(y - r - 1, A);
     load_row(min(y + r, H - 1), B);
     for (;;) {
         if (!link(A, B)) break;
