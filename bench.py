@@ -32,10 +32,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=128, help="frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
     ap.add_argument("--rows", type=int, default=1080)
     ap.add_argument("--cols", type=int, default=1920)
-    ap.add_argument("--streams", type=int, default=2, help="independent half-batches in flight per GPU (HIP streams + host threads)")
+    ap.add_argument("--streams", type=int, default=4, help="independent sub-batches in flight per GPU (HIP streams + host threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=540)
     ap.add_argument("--cpu-sample-cols", type=int, default=960)
