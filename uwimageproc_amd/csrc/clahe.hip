@@ -181,8 +181,7 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
             int excess = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { excess += max(h[k] - clip, 0); h[k] = min(h[k], clip); }
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) excess += __shfl_xor(excess, d, 64);
+            excess = (int)wave_sum_u32((uint32_t)excess);
             const int batch = excess / 256;
             const int residual = excess - batch * 256;
             const int stepr = residual ? max(256 / residual, 1) : 1;
@@ -197,13 +196,7 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
             }
         }
         const int p0 = h[0], p1 = p0 + h[1], p2 = p1 + h[2], p3 = p2 + h[3];
-        int incl = p3;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += o;
-        }
-        const int off = incl - p3;
+        const int off = (int)wave_incl_scan_u32((uint32_t)p3) - p3;
         const uint32_t w = sat_u8_rne((float)(off + p0) * lutScale) | (sat_u8_rne((float)(off + p1) * lutScale) << 8) |
                            (sat_u8_rne((float)(off + p2) * lutScale) << 16) | (sat_u8_rne((float)(off + p3) * lutScale) << 24);
         *reinterpret_cast<uint32_t *>(luts + (((size_t)f * ncl + c) * tiles + t) * 256 + lane * 4) = w;

@@ -25,15 +25,28 @@ __device__ __forceinline__ int reflect101(int p, int len)
 
 // Inclusive scan / sum over a 256-thread block of uint32 (4 waves).
 // `scratch` must hold >= 8 uint32 in LDS.  All 256 threads must call.
+// Inclusive prefix over the 64 lanes of a wave by DPP (no LDS traffic, unlike __shfl_up): Hillis-Steele inside each
+// row of 16 lanes (row_shr 1,2,4,8), then row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3; lanes without a
+// source read 0.  All 64 lanes must be active.
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ uint32_t uwip_dpp0_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWMASK, 0xf, true);
+}
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v)
 {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+    v += uwip_dpp0_u32<0x111, 0xf>(v);
+    v += uwip_dpp0_u32<0x112, 0xf>(v);
+    v += uwip_dpp0_u32<0x114, 0xf>(v);
+    v += uwip_dpp0_u32<0x118, 0xf>(v);
+    v += uwip_dpp0_u32<0x142, 0xa>(v);
+    v += uwip_dpp0_u32<0x143, 0xc>(v);
     return v;
+}
+// sum over the wave, returned in every lane
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan_u32(v), 63);
 }
 
 __device__ __forceinline__ uint32_t block256_incl_scan_u32(uint32_t v, uint32_t *scratch)
@@ -47,13 +60,6 @@ __device__ __forceinline__ uint32_t block256_incl_scan_u32(uint32_t v, uint32_t 
 #pragma unroll
     for (int w = 0; w < 3; ++w) off += (w < wave) ? scratch[w] : 0u;
     return s + off;
-}
-
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
 }
 
 __device__ __forceinline__ uint32_t block256_sum_u32(uint32_t v, uint32_t *scratch)
