@@ -37,7 +37,6 @@ def parse():
     ap.add_argument("--cols", type=int, default=1920)
     ap.add_argument("--streams", type=int, default=4, help="independent sub-batches in flight per GPU (HIP streams + host threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pcie", action="store_true", help="also time the steps with pinned-host <-> HBM copies of every frame (N=1 only)")
     ap.add_argument("--cpu-sample-rows", type=int, default=540)
     ap.add_argument("--cpu-sample-cols", type=int, default=960)
     return ap.parse_args()
@@ -172,41 +171,6 @@ def main():
     from uwimageproc_amd import sharding
     dt = sharding.max_over_ranks(dt)          # the slowest rank defines the step time
 
-    # Host-buffer variant (reported next to `value`, never as `value`): every step also copies its frames from pinned
-    # host memory to HBM and the processed frames back, on the sub-batch's own stream.
-    pcie = None
-    if world == 1 and args.pcie:
-        h_in = [p.cpu().pin_memory() for p in parts]
-        # pinned on purpose: an asynchronous device-to-host copy into PAGEABLE memory from several host threads faulted
-        # the GPU on this stack (the runtime's on-the-fly pinning raced with the copies)
-        h_out = [torch.empty(h.shape, dtype=h.dtype, pin_memory=True) for h in h_in]
-        d_in = [torch.empty_like(p) for p in parts]
-
-        def run_step_pcie():
-            import threading
-            def work(i):
-                with torch.cuda.stream(streams[i]):
-                    d_in[i].copy_(h_in[i], non_blocking=True)
-                    out, _ = pipes[i].run(d_in[i])
-                    h_out[i].copy_(out, non_blocking=True)
-            th = [threading.Thread(target=work, args=(i,)) for i in range(1, S)]
-            for t in th:
-                t.start()
-            work(0)
-            for t in th:
-                t.join()
-
-        run_step_pcie()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            run_step_pcie()
-        torch.cuda.synchronize()
-        dt_p = time.perf_counter() - t1
-        pcie = {"value": F * args.steps / dt_p, "unit": "frames/s", "ms_per_step": dt_p / args.steps * 1e3,
-                "note": "same steps with pinned-host -> HBM and HBM -> pinned-host copies of every frame on the sub-batch's stream"}
-        del h_in, h_out, d_in
-
     # per-kernel timing pass (HIP events on the launch stream, inside libuwip)
     roof = None
     kernels = {}
@@ -260,7 +224,6 @@ def main():
                        "parallelism": f"frame-batch x{world}"},
             "roofline": roof,
             "cpu_baseline": cpu,
-            "host_buffers": pcie,
             "kernels": kernels,
         }
         print(json.dumps(line))
