@@ -101,21 +101,39 @@ __global__ void k_ov_gray_to_L0(const uint8_t *__restrict__ gray, float *__restr
 }
 
 // ---- separable Gaussian, reflect-101 border ----------------------------------------------
-template <bool ALONG_X>
-__global__ __launch_bounds__(256) void k_ov_conv(const float *__restrict__ in, float *__restrict__ out, int h, int w,
-                                                ConvK K)
+// Both passes of the separable Gaussian in one launch: a block owns a 64 x 16 output tile, stages the tile + halo once
+// (reflect-101 applied to the global indices), convolves along x into a second LDS plane (tile rows + halo rows) and
+// along y out of it.  Every output goes through the same multiplies and adds in the same order as the two-pass form
+// (the intermediate row of image row reflect101(y) is what the y pass of the two-pass form reads there).
+constexpr int CV_TW = 64, CV_TH = 16, CV_RMAX = 7;
+__global__ __launch_bounds__(256) void k_ov_conv2(const float *__restrict__ in, float *__restrict__ out, int h, int w, ConvK K)
 {
-    const int f = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
+    __shared__ float s_in[(CV_TH + 2 * CV_RMAX) * (CV_TW + 2 * CV_RMAX)];
+    __shared__ float s_tmp[(CV_TH + 2 * CV_RMAX) * CV_TW];
+    const int f = blockIdx.z, x0 = blockIdx.x * CV_TW, y0 = blockIdx.y * CV_TH;
     const float *I = in + (size_t)f * h * w;
-    const int r = K.ks / 2;
-    float acc = 0.0f;
-    for (int i = 0; i < K.ks; ++i) {
-        const float v = ALONG_X ? I[(size_t)y * w + reflect101(x + i - r, w)] : I[(size_t)reflect101(y + i - r, h) * w + x];
-        acc = acc + K.k[i] * v;
+    const int r = K.ks / 2, RW = CV_TW + 2 * r, RH = CV_TH + 2 * r;
+    for (int i = threadIdx.x; i < RH * RW; i += 256) {
+        const int ry = i / RW, rx = i - ry * RW;
+        s_in[i] = I[(size_t)reflect101(y0 - r + ry, h) * w + reflect101(x0 - r + rx, w)];
     }
-    out[((size_t)f * h + y) * w + x] = acc;
+    __syncthreads();
+    for (int i = threadIdx.x; i < RH * CV_TW; i += 256) {
+        const int ry = i / CV_TW, tx = i - ry * CV_TW;
+        const float *row = s_in + ry * RW + tx;
+        float acc = 0.0f;
+        for (int k = 0; k < K.ks; ++k) acc = acc + K.k[k] * row[k];
+        s_tmp[i] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CV_TH * CV_TW; i += 256) {
+        const int ty = i / CV_TW, tx = i - ty * CV_TW;
+        const float *col = s_tmp + ty * CV_TW + tx;
+        float acc = 0.0f;
+        for (int k = 0; k < K.ks; ++k) acc = acc + K.k[k] * col[k * CV_TW];
+        const int x = x0 + tx, y = y0 + ty;
+        if (x < w && y < h) out[((size_t)f * h + y) * w + x] = acc;
+    }
 }
 
 __device__ __forceinline__ void scharr_at(const float *I, int h, int w, int y, int x, float &gx, float &gy)
@@ -1199,7 +1217,7 @@ dim3 grid2d(int w, int h, int z) { return dim3(uwip_cdiv(w, 64), uwip_cdiv(h, 4)
 
 struct OvWork {
     uint8_t *gray;
-    float *L0, *tmp, *Lsm, *flow, *ping, *Lt, *Lx, *Ly, *Ldet, *cand, *kc;
+    float *L0, *Lsm, *flow, *ping, *Lt, *Lx, *Ly, *Ldet, *cand, *kc;
     uint32_t *hmax, *khist, *selhist, *sel, *counts;
 };
 
@@ -1209,7 +1227,6 @@ int alloc_work(uwip_ctx *ctx, int F, int h, int w, OvWork *W)
     const int nchunks = (int)((n * NLEV + CMP_CHUNK - 1) / CMP_CHUNK);
     W->gray = (uint8_t *)uwip_ws(ctx, "ov.gray", n * F);
     W->L0 = (float *)uwip_ws(ctx, "ov.L0", n * F * 4);
-    W->tmp = (float *)uwip_ws(ctx, "ov.tmp", n * F * 4);
     W->Lsm = (float *)uwip_ws(ctx, "ov.Lsm", n * F * 4);
     W->flow = (float *)uwip_ws(ctx, "ov.flow", n * F * 4);
     W->ping = (float *)uwip_ws(ctx, "ov.ping", n * F * 4);
@@ -1224,7 +1241,7 @@ int alloc_work(uwip_ctx *ctx, int F, int h, int w, OvWork *W)
     W->selhist = (uint32_t *)uwip_ws(ctx, "ov.selhist", sizeof(uint32_t) * 65536 * F);
     W->sel = (uint32_t *)uwip_ws(ctx, "ov.sel", sizeof(uint32_t) * 4 * F);
     W->counts = (uint32_t *)uwip_ws(ctx, "ov.counts", sizeof(uint32_t) * nchunks * F);
-    if (!W->gray || !W->L0 || !W->tmp || !W->Lsm || !W->flow || !W->ping || !W->Lt || !W->Lx || !W->Ly || !W->Ldet || !W->cand ||
+    if (!W->gray || !W->L0 || !W->Lsm || !W->flow || !W->ping || !W->Lt || !W->Lx || !W->Ly || !W->Ldet || !W->cand ||
         !W->kc || !W->hmax || !W->khist || !W->selhist || !W->sel || !W->counts)
         return UWIP_ERR_NOMEM;
     return UWIP_OK;
@@ -1241,12 +1258,12 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
     {
         uwip_kscope ks(ctx, "k_ov_scale_space");
         const ConvK K0 = gauss_kernel(H_SIGMA[0]), K1 = gauss_kernel(1.0f);
-        k_ov_conv<true><<<g, 256, 0, ctx->stream>>>(W.L0, W.tmp, h, w, K0);
-        k_ov_conv<false><<<g, 256, 0, ctx->stream>>>(W.tmp, W.Lt, h, w, K0);
+        UWIP_REQUIRE(ctx, K0.ks / 2 <= CV_RMAX && K1.ks / 2 <= CV_RMAX && (K0.ks & 1) && (K1.ks & 1), "Gaussian kernel too wide for k_ov_conv2");
+        const dim3 gc(uwip_cdiv(w, CV_TW), uwip_cdiv(h, CV_TH), (unsigned)F);
+        k_ov_conv2<<<gc, 256, 0, ctx->stream>>>(W.L0, W.Lt, h, w, K0);
         for (int lv = 0; lv < NLEV; ++lv) {
             float *Lt = W.Lt + lv * lvl;
-            k_ov_conv<true><<<g, 256, 0, ctx->stream>>>(Lt, W.tmp, h, w, K1);
-            k_ov_conv<false><<<g, 256, 0, ctx->stream>>>(W.tmp, W.Lsm, h, w, K1);
+            k_ov_conv2<<<gc, 256, 0, ctx->stream>>>(Lt, W.Lsm, h, w, K1);
             if (lv == 0) {
                 const int nbk = (int)(g.x * g.y);
                 uint32_t *kpart = (uint32_t *)uwip_ws(ctx, "ov.kcpart", sizeof(uint32_t) * nbk * F);
