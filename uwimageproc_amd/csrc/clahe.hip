@@ -158,6 +158,18 @@ __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restric
     if (s) atomicAdd(&hists[((size_t)f * tiles + t) * 256 + tid], s);
 }
 
+// Histograms of a g x g grid from those of the 2g x 2g grid when neither is padded (a tile is then exactly four
+// tiles of the finer grid): no second pass over the image.
+__global__ __launch_bounds__(256) void k_clahe_tilehist_merge(const uint32_t *__restrict__ child, int gx, int tiles,
+                                                              uint32_t *__restrict__ hists)
+{
+    const int t = blockIdx.x, f = blockIdx.y, v = threadIdx.x;
+    const int ty = t / gx, tx = t - ty * gx, gx2 = 2 * gx;
+    const uint32_t *c = child + (size_t)f * tiles * 4 * 256;
+    const size_t c00 = (size_t)(2 * ty) * gx2 + 2 * tx;
+    hists[((size_t)f * tiles + t) * 256 + v] = c[c00 * 256 + v] + c[(c00 + 1) * 256 + v] + c[(c00 + gx2) * 256 + v] + c[(c00 + gx2 + 1) * 256 + v];
+}
+
 // ---- C1b: clip, redistribute, cumulative LUT --------------------------------
 // One wave per (tile, frame); lane l owns bins 4l..4l+3 and the wave walks all clip limits with shuffle-only
 // reductions and scans (no barriers).  Arithmetic is cv::CLAHE's: integer clip / redistribute, then
@@ -738,18 +750,34 @@ UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int resi
     UWIP_REQUIRE(ctx, d_entropy != nullptr, "null output");
     UWIP_REQUIRE(ctx, !uwip_batch_empty(src), "sweep of an empty image");
     UWIP_REQUIRE(ctx, src->frames <= 65535, "too many frames for one launch");
+    // k_clahe_sweep counts in 16-bit LDS counters: a block must see < 65536 pixels, and its smallest work item is one
+    // row of an interpolation cell (at most a tile wide)
+    UWIP_REQUIRE(ctx, src->cols <= 65535, "image too wide for the sweep");
     const int F = src->frames;
     const size_t out_fs = (size_t)5 * SWEEP_NCL * 256;
     uint32_t *d_out = (uint32_t *)uwip_ws(ctx, "sweep.outhist", sizeof(uint32_t) * out_fs * F);
-    uint32_t *d_hists = (uint32_t *)uwip_ws(ctx, "clahe.tilehist", sizeof(uint32_t) * 256 * (size_t)1024 * F);
+    uint32_t *hbuf[2] = {(uint32_t *)uwip_ws(ctx, "clahe.tilehist", sizeof(uint32_t) * 256 * (size_t)1024 * F),
+                         (uint32_t *)uwip_ws(ctx, "clahe.tilehist2", sizeof(uint32_t) * 256 * (size_t)1024 * F)};
     uint8_t *d_luts = (uint8_t *)uwip_ws(ctx, "sweep.luts", (size_t)256 * 1024 * SWEEP_NCL * F);
-    if (!d_out || !d_hists || !d_luts) return UWIP_ERR_NOMEM;
+    if (!d_out || !hbuf[0] || !hbuf[1] || !d_luts) return UWIP_ERR_NOMEM;
     UWIP_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(uint32_t) * out_fs * F, ctx->stream));
-    for (int gi = 0; gi < 5; ++gi) {
+    // finest grid first: a coarser unpadded grid sums the tile histograms of the grid twice as fine
+    ClaheGeom finer{};
+    for (int gi = 4; gi >= 0; --gi) {
         const int gsz = BlockSize[gi];
         const ClaheGeom g = make_geom(src->rows, src->cols, gsz, gsz);
-        rc = launch_tilehist(ctx, src, g, nullptr, F, d_hists);
-        if (rc) return rc;
+        uint32_t *d_hists = hbuf[gi & 1];
+        const bool nested = gi < 4 && finer.gx == 2 * g.gx && finer.gy == 2 * g.gy && finer.pc == finer.cols && finer.pr == finer.rows &&
+                            g.pc == g.cols && g.pr == g.rows && finer.tw * 2 == g.tw && finer.th * 2 == g.th;
+        if (nested) {
+            uwip_kscope ks(ctx, "k_clahe_tilehist");
+            k_clahe_tilehist_merge<<<dim3((unsigned)(g.gx * g.gy), (unsigned)F), 256, 0, ctx->stream>>>(hbuf[(gi + 1) & 1], g.gx, g.gx * g.gy, d_hists);
+            UWIP_HIP(ctx, hipGetLastError());
+        } else {
+            rc = launch_tilehist(ctx, src, g, nullptr, F, d_hists);
+            if (rc) return rc;
+        }
+        finer = g;
         ClipList cl{};
         cl.n = 0;
         for (float c = 0.0f; c <= 25.0f; c += 0.5f) cl.clip[cl.n++] = clip_from_limit((double)c, g.area);
