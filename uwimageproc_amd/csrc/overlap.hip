@@ -256,6 +256,62 @@ __global__ __launch_bounds__(256) void k_ov_fed(const float *__restrict__ Lin, c
     out[(size_t)f * h * w + i] = L[i] + step * d;
 }
 
+// Two consecutive FED steps in one launch: a block stages L and the conductivity of its 64 x 16 tile + 2 halo pixels
+// (loaded at edge-clamped coordinates, which is exactly the neighbour rule of k_ov_fed), takes step 1 on the tile + 1
+// halo into LDS and step 2 out of it.  Every value goes through the same operations in the same order as two
+// k_ov_fed launches.
+constexpr int FD_TW = 64, FD_TH = 16;
+__device__ __forceinline__ float fed_px(float Lc, float Lxm, float Lxp, float Lym, float Lyp, float cc, float cxm, float cxp,
+                                        float cym, float cyp, float step)
+{
+    const float xpos = (cc + cxp) * (Lxp - Lc);
+    const float xneg = (cxm + cc) * (Lc - Lxm);
+    const float ypos = (cc + cyp) * (Lyp - Lc);
+    const float yneg = (cym + cc) * (Lc - Lym);
+    float d = xpos - xneg;
+    d = d + ypos;
+    d = d - yneg;
+    return Lc + step * d;
+}
+__global__ __launch_bounds__(256) void k_ov_fed2(const float *__restrict__ Lin, const float *__restrict__ cin, float *__restrict__ out,
+                                                int h, int w, float tau1, float tau2)
+{
+    constexpr int W2 = FD_TW + 4, H2 = FD_TH + 4, W1 = FD_TW + 2, H1 = FD_TH + 2;
+    __shared__ float s_L[H2 * W2], s_c[H2 * W2], s_M[H1 * W1];
+    const int f = blockIdx.z, x0 = blockIdx.x * FD_TW, y0 = blockIdx.y * FD_TH;
+    const float *L = Lin + (size_t)f * h * w, *c = cin + (size_t)f * h * w;
+    for (int i = threadIdx.x; i < H2 * W2; i += 256) {
+        const int ry = i / W2, rx = i - ry * W2;
+        const int y = min(max(y0 - 2 + ry, 0), h - 1), x = min(max(x0 - 2 + rx, 0), w - 1);
+        s_L[i] = L[(size_t)y * w + x];
+        s_c[i] = c[(size_t)y * w + x];
+    }
+    __syncthreads();
+    const float step1 = 0.5f * tau1, step2 = 0.5f * tau2;
+    // step 1 at tile + 1 halo: local (ly, lx) of s_M is local (ly + 1, lx + 1) of s_L
+    for (int i = threadIdx.x; i < H1 * W1; i += 256) {
+        const int ly = i / W1, lx = i - ly * W1;
+        const int o = (ly + 1) * W2 + lx + 1;
+        s_M[i] = fed_px(s_L[o], s_L[o - 1], s_L[o + 1], s_L[o - W2], s_L[o + W2], s_c[o], s_c[o - 1], s_c[o + 1], s_c[o - W2],
+                        s_c[o + W2], step1);
+    }
+    __syncthreads();
+    // step 2 on the tile: the neighbours of an image-border pixel are the pixel itself (indices clamped in the image)
+    for (int i = threadIdx.x; i < FD_TH * FD_TW; i += 256) {
+        const int ty = i / FD_TW, tx = i - ty * FD_TW;
+        const int x = x0 + tx, y = y0 + ty;
+        if (x >= w || y >= h) continue;
+        const int xm = max(x - 1, 0) - (x0 - 1), xp = min(x + 1, w - 1) - (x0 - 1);
+        const int ym = max(y - 1, 0) - (y0 - 1), yp = min(y + 1, h - 1) - (y0 - 1);
+        const int mx = tx + 1, my = ty + 1;
+        // conductivity from the clamped-load plane: local (ly, lx) of s_M is (ly + 1, lx + 1) of s_c
+        out[((size_t)f * h + y) * w + x] =
+            fed_px(s_M[my * W1 + mx], s_M[my * W1 + xm], s_M[my * W1 + xp], s_M[ym * W1 + mx], s_M[yp * W1 + mx],
+                   s_c[(my + 1) * W2 + mx + 1], s_c[(my + 1) * W2 + xm + 1], s_c[(my + 1) * W2 + xp + 1],
+                   s_c[(ym + 1) * W2 + mx + 1], s_c[(yp + 1) * W2 + mx + 1], step2);
+    }
+}
+
 // ---- scale-s first derivative (taps at -s, 0, +s) ------------------------------------------------
 __device__ __forceinline__ float deriv_at(const float *I, int h, int w, int y, int x, int s, bool along_x)
 {
@@ -1282,14 +1338,22 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
                 const float e0 = 0.5f * H_SIGMA[lv] * H_SIGMA[lv], e1 = 0.5f * H_SIGMA[lv + 1] * H_SIGMA[lv + 1];
                 float taus[32];
                 const int nt = fed_taus(e1 - e0, taus);
-                // ping-pong between Lt[lv+1] and a scratch plane so that the last step lands in Lt[lv+1]
+                // two steps per launch (one for an odd remainder); ping-pong between Lt[lv+1] and a scratch plane so
+                // that the last launch lands in Lt[lv+1]
                 float *next = W.Lt + (lv + 1) * lvl;
                 const float *src = Lt;
-                float *dst = (nt & 1) ? next : W.ping;
-                for (int k = 0; k < nt; ++k) {
-                    k_ov_fed<<<g, 256, 0, ctx->stream>>>(src, W.flow, dst, h, w, taus[k]);
+                const int nl = (nt + 1) / 2;
+                const dim3 gf(uwip_cdiv(w, FD_TW), uwip_cdiv(h, FD_TH), (unsigned)F);
+                for (int j = 0, k = 0; j < nl; ++j) {
+                    float *dst = ((nl - j) & 1) ? next : W.ping;
+                    if (k + 1 < nt) {
+                        k_ov_fed2<<<gf, 256, 0, ctx->stream>>>(src, W.flow, dst, h, w, taus[k], taus[k + 1]);
+                        k += 2;
+                    } else {
+                        k_ov_fed<<<g, 256, 0, ctx->stream>>>(src, W.flow, dst, h, w, taus[k]);
+                        k += 1;
+                    }
                     src = dst;
-                    dst = (dst == next) ? W.ping : next;
                 }
             }
         }
