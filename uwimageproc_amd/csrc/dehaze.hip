@@ -38,6 +38,15 @@ enum { SI_MN = 0, SI_MX = 1, SI_RMN = 2, SI_RMX = 3, SI_YJMN = 4, SI_YJMX = 5, S
 constexpr int RED_BLOCKS = 128;   // blocks per frame for the streaming reduction kernels
 
 __device__ __forceinline__ double normv(int v, int mn, int mx) { return (double)(v - mn) / (double)(mx - mn); }
+// An 8-bit sample takes 256 values, so every per-sample expression of the frame scalars is a 256-entry table: the
+// block's 256 threads evaluate it once (same operations, same roundings) and the pixel loop looks it up in LDS
+// instead of running float64 divisions per pixel.  Call with all 256 threads; ends with a barrier.
+template <class F>
+__device__ __forceinline__ void fill_table256(double *tab, F f)
+{
+    tab[threadIdx.x] = f((int)threadIdx.x);
+    __syncthreads();
+}
 
 __device__ __forceinline__ double block_reduce_f64(double v, int op /*0 sum 1 min 2 max*/, double *scratch)
 {
@@ -199,10 +208,12 @@ __global__ __launch_bounds__(256) void k_bglight_partial(const uint8_t *__restri
     const uint8_t *pB = mx + (size_t)f * 3 * n, *pG = pB + n, *pR = pG + n;
     double best0 = 1e300, best1 = 1e300;
     int i0 = 0x7fffffff, i1 = 0x7fffffff;
+    __shared__ double s_T[256];
+    fill_table256(s_T, [&](int v) { return normv(v, mn, mxv); });
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const double r = normv(pR[i], mn, mxv);
-        const double d0 = r - normv(pB[i], mn, mxv);
-        const double d1 = r - normv(pG[i], mn, mxv);
+        const double r = s_T[pR[i]];
+        const double d0 = r - s_T[pB[i]];
+        const double d1 = r - s_T[pG[i]];
         if (d0 < best0) { best0 = d0; i0 = (int)i; }     // i increases per thread: keeps the first
         if (d1 < best1) { best1 = d1; i1 = (int)i; }
     }
@@ -264,12 +275,15 @@ __global__ __launch_bounds__(256) void k_transmission(const uint8_t *__restrict_
     const double B0 = sc[(size_t)f * SC_COUNT + SC_B0], B1 = sc[(size_t)f * SC_COUNT + SC_B1];
     const size_t n = (size_t)H * W;
     const uint8_t *m0 = mnp + (size_t)f * 3 * n, *m1 = m0 + n;
+    __shared__ double s_Q0[256], s_Q1[256];
+    s_Q0[threadIdx.x] = normv((int)threadIdx.x, mn, mx) / B0;
+    fill_table256(s_Q1, [&](int v) { return normv(v, mn, mx) / B1; });
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
         // zero padding (BGDehaze.py:32): a window that leaves the image contains a 0
         const bool inside = (y - pad >= 0) && (y - pad + w <= H) && (x - pad >= 0) && (x - pad + w <= W);
-        const double q0 = inside ? normv(m0[i], mn, mx) / B0 : 0.0;
-        const double q1 = inside ? normv(m1[i], mn, mx) / B1 : 0.0;
+        const double q0 = inside ? s_Q0[m0[i]] : 0.0;
+        const double q1 = inside ? s_Q1[m1[i]] : 0.0;
         const double t0 = 1.0 - q0, t1 = 1.0 - q1;
         if (traw) { traw[(size_t)f * 2 * n + i] = t0; traw[(size_t)f * 2 * n + n + i] = t1; }
         P[(size_t)f * 2 * n + i] = fmax(t0, tmin);
@@ -291,14 +305,16 @@ __global__ __launch_bounds__(256) void k_recover(const uint8_t *__restrict__ img
     double *q0 = Q + (size_t)f * 2 * n, *q1 = q0 + n;
     const uint8_t *b = img + (size_t)f * fs;
     double mn0 = 1e300, mx0 = -1e300, mn1 = 1e300, mx1 = -1e300, sr = 0.0;
+    __shared__ double s_T[256];
+    fill_table256(s_T, [&](int v) { return normv(v, mn, mx); });
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
         const uint8_t *p = b + (size_t)y * step + (size_t)x * 3;
-        const double j0 = (normv(p[0], mn, mx) - B0) / q0[i] + B0;
-        const double j1 = (normv(p[1], mn, mx) - B1) / q1[i] + B1;
+        const double j0 = (s_T[p[0]] - B0) / q0[i] + B0;
+        const double j1 = (s_T[p[1]] - B1) / q1[i] + B1;
         q0[i] = j0; q1[i] = j1;
         mn0 = fmin(mn0, j0); mx0 = fmax(mx0, j0); mn1 = fmin(mn1, j1); mx1 = fmax(mx1, j1);
-        sr += normv(p[2], mn, mx);
+        sr += s_T[p[2]];
     }
     double *o = part + ((size_t)f * gridDim.x + blockIdx.x) * 5;
     const double a = block_reduce_f64(mn0, 1, scratch), bb = block_reduce_f64(mx0, 2, scratch);
@@ -363,13 +379,20 @@ __global__ void k_normJ_final(const double *__restrict__ part, int nb, const int
     s[SC_RMIN] = fmin(lo, hi); s[SC_RMAX] = fmax(lo, hi);
 }
 
+// the compensated, min-max normalised red channel as a function of the 8-bit red value (BGDehaze.py:61-64)
+__device__ __forceinline__ void fill_red_table(double *tab, const double *s, int mn, int mx)
+{
+    fill_table256(tab, [&](int v) {
+        const double rrec = normv(v, mn, mx) * s[SC_COEFF];
+        return (rrec - s[SC_RMIN]) / (s[SC_RMAX] - s[SC_RMIN]);
+    });
+}
 __device__ __forceinline__ void restored_px(const uint8_t *p, const double *nJ0, const double *nJ1, size_t i,
-                                            const double *s, int mn, int mx, double out[3])
+                                            const double *s, const double *red_tab, double out[3])
 {
     out[0] = (nJ0[i] - s[SC_JMIN0]) / (s[SC_JMAX0] - s[SC_JMIN0]);   // min-max normalised J (BGDehaze.py:54,56)
     out[1] = (nJ1[i] - s[SC_JMIN1]) / (s[SC_JMAX1] - s[SC_JMIN1]);
-    const double rrec = normv(p[2], mn, mx) * s[SC_COEFF];
-    out[2] = (rrec - s[SC_RMIN]) / (s[SC_RMAX] - s[SC_RMIN]);
+    out[2] = red_tab[p[2]];
 }
 
 __device__ __forceinline__ uint8_t f64_to_u8_rne(double v)
@@ -392,11 +415,13 @@ __global__ __launch_bounds__(256) void k_rc_out(const uint8_t *__restrict__ img,
     const int mn = si[(size_t)f * SI_COUNT + SI_MN], mx = si[(size_t)f * SI_COUNT + SI_MX];
     const double *s = sc + (size_t)f * SC_COUNT;
     const double *q0 = Q + (size_t)f * 2 * n, *q1 = q0 + n;
+    __shared__ double s_red[256];
+    fill_red_table(s_red, s, mn, mx);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
         const uint8_t *p = img + (size_t)f * fs + (size_t)y * step + (size_t)x * 3;
         double v[3];
-        restored_px(p, q0, q1, i, s, mn, mx, v);
+        restored_px(p, q0, q1, i, s, s_red, v);
         if (tap) { double *t = tap + ((size_t)f * n + i) * 3; t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; }
         if (out) {
             uint8_t *o = out + (size_t)f * ofs + (size_t)y * ostep + (size_t)x * 3;
@@ -430,14 +455,18 @@ __global__ __launch_bounds__(256) void k_exp_prep(const uint8_t *__restrict__ im
     const double *s = sc + (size_t)f * SC_COUNT;
     const double *q0 = Q + (size_t)f * 2 * n, *q1 = q0 + n;
     int jmn = 255, jmx = 0, imn = 255, imx = 0;
+    __shared__ double s_red[256];
+    __shared__ int s_u8[256];     // (normalised input * 255).astype(uint8) per 8-bit value
+    s_u8[threadIdx.x] = trunc_u8(normv((int)threadIdx.x, mn, mx));
+    fill_red_table(s_red, s, mn, mx);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
         const uint8_t *p = img + (size_t)f * fs + (size_t)y * step + (size_t)x * 3;
         double v[3];
-        restored_px(p, q0, q1, i, s, mn, mx, v);
+        restored_px(p, q0, q1, i, s, s_red, v);
         int Yj, Crj, Cbj, Yi, Cri, Cbi;
         bgr2ycrcb(trunc_u8(v[0]), trunc_u8(v[1]), trunc_u8(v[2]), Yj, Crj, Cbj);
-        bgr2ycrcb(trunc_u8(normv(p[0], mn, mx)), trunc_u8(normv(p[1], mn, mx)), trunc_u8(normv(p[2], mn, mx)), Yi, Cri, Cbi);
+        bgr2ycrcb(s_u8[p[0]], s_u8[p[1]], s_u8[p[2]], Yi, Cri, Cbi);
         uint8_t *o = YI + ((size_t)f * n + i) * 3;
         o[0] = (uint8_t)Yi; o[1] = (uint8_t)Cri; o[2] = (uint8_t)Cbi;
         YJ[(size_t)f * n + i] = (uint8_t)Yj;
@@ -463,9 +492,12 @@ __global__ __launch_bounds__(256) void k_exp_S(const uint8_t *__restrict__ YI, c
     const int f = blockIdx.y;
     const int *ii = si + (size_t)f * SI_COUNT;
     const int jmn = ii[SI_YJMN], jmx = ii[SI_YJMX], imn = ii[SI_YIMN], imx = ii[SI_YIMX];
+    __shared__ double s_Ti[256], s_Tj[256];
+    s_Ti[threadIdx.x] = normv((int)threadIdx.x, imn, imx);
+    fill_table256(s_Tj, [&](int v) { return normv(v, jmn, jmx); });
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const double Yi = normv(YI[((size_t)f * n + i) * 3], imn, imx);
-        const double Yj = normv(YJ[(size_t)f * n + i], jmn, jmx);
+        const double Yi = s_Ti[YI[((size_t)f * n + i) * 3]];
+        const double Yj = s_Tj[YJ[(size_t)f * n + i]];
         const double num = Yj * Yi + 0.3 * (Yi * Yi), den = Yj * Yj + 0.3 * (Yi * Yi);
         // as written, 0/0 = NaN poisons the whole frame; the guard is an opt-in deviation
         S[(size_t)f * n + i] = (guard && den == 0.0) ? 1.0 : num / den;
@@ -489,11 +521,13 @@ __global__ __launch_bounds__(256) void k_exp_out(const uint8_t *__restrict__ img
     const double *q0 = Q + (size_t)f * 2 * n, *q1 = q0 + n;
     const double omn = s[SC_OMN], od = s[SC_OMX] - s[SC_OMN];
     double lo = 1e300, hi = -1e300, nanflag = 0.0;
+    __shared__ double s_red[256];
+    fill_red_table(s_red, s, mn, mx);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
         const uint8_t *p = img + (size_t)f * fs + (size_t)y * step + (size_t)x * 3;
         double v[3];
-        restored_px(p, q0, q1, i, s, mn, mx, v);
+        restored_px(p, q0, q1, i, s, s_red, v);
         const double rs = RS[(size_t)f * n + i];
         v[0] *= rs; v[1] *= rs; v[2] *= rs;
         if (PASS == 0) {
