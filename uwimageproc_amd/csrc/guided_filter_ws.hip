@@ -63,6 +63,10 @@ __device__ __forceinline__ void wave_lds_fence()
 }
 
 __device__ __forceinline__ int byte_of(const uint32_t (&g)[3], int k) { return (int)((g[k >> 2] >> ((k & 3) * 8)) & 0xffu); }
+// three dwords as ONE value (a 96-bit register tuple): what a dwordx3 load produces, so a loop-carried row buffer of
+// this type needs no per-element copies behind the load
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ int byte_of(const u32x3 &g, int k) { return (int)((g[k >> 2] >> ((k & 3) * 8)) & 0xffu); }
 
 // Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share an L2).  Give every XCD a contiguous range of
 // the logical (strip, y, z) index space instead, so that neighbouring strips -- which share 2r halo columns -- run
@@ -87,7 +91,7 @@ struct StripGeom {
     bool lo_ok[4];       // c - r - 1 >= 0 (else G = 0)
     __device__ __forceinline__ void init(int bx, int TS, int r, int W)
     {
-        l = threadIdx.x;
+        l = threadIdx.x & 63;
         x0 = bx * TS - r + 4 * l;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -118,7 +122,7 @@ __device__ __forceinline__ double count_of(int lo, int hi, int n) { return (doub
 // ---- a, b ---------------------------------------------------------------------------------------------
 template <int NP>
 struct SolveRow {
-    uint32_t g[3];      // 4 columns x 3 bytes of the guide
+    u32x3 g;            // 4 columns x 3 bytes of the guide
     double p[NP][4];
 };
 
@@ -162,18 +166,23 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
     // A row buffer is cleared ONCE (guide bytes = mn, p = 0: contributes nothing); load_row then only overwrites the
     // lanes / columns that are inside the image, so out-of-image columns stay neutral without a per-row refill.
     auto clear_row = [&](SolveRow<NP> &R) {
-        R.g[0] = R.g[1] = R.g[2] = fillw;
+        R.g = u32x3{fillw, fillw, fillw};
 #pragma unroll
         for (int ip = 0; ip < NP; ++ip) R.p[ip][0] = R.p[ip][1] = R.p[ip][2] = R.p[ip][3] = 0.0;
     };
     // per-lane bases; the row offsets below are wave-uniform (scalar) products
     const uint8_t *g_lane = gf + (size_t)(sg.in[0] ? sg.x0 : 0) * 3;
     const double *p_lane = pin + (sg.in[0] ? sg.x0 : 0);
+    // VEC: every lane loads unconditionally (lanes outside the image read the row's first columns and are neutralised in
+    // accum by mn_l / pm): a load under a lane mask has to be merged with the register's old contents, and that merge
+    // sits right behind the load -- it made every row wait for its own prefetch.
+    const int mn_l = (VEC && !sg.in[0]) ? 255 : mn;
+    const double pm = (VEC && !sg.in[0]) ? 0.0 : 1.0;
     auto load_row = [&](int yy, SolveRow<NP> &R) {   // yy must be a row of the image
         if (VEC) {
-            if (sg.in[0]) {
+            {
                 const uint32_t *q = reinterpret_cast<const uint32_t *>(g_lane + (size_t)yy * step);
-                R.g[0] = q[0]; R.g[1] = q[1]; R.g[2] = q[2];
+                R.g = *reinterpret_cast<const u32x3 *>(q);
 #pragma unroll
                 for (int ip = 0; ip < NP; ++ip) {
                     const double2 *pp = reinterpret_cast<const double2 *>(p_lane + ((size_t)ip * H + yy) * W);
@@ -200,8 +209,8 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
         constexpr bool ADD = decltype(add_tag)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t a = (uint32_t)max(byte_of(R.g, 3 * j) - mn, 0), b = (uint32_t)max(byte_of(R.g, 3 * j + 1) - mn, 0),
-                           c = (uint32_t)max(byte_of(R.g, 3 * j + 2) - mn, 0);
+            const uint32_t a = (uint32_t)max(byte_of(R.g, 3 * j) - mn_l, 0), b = (uint32_t)max(byte_of(R.g, 3 * j + 1) - mn_l, 0),
+                           c = (uint32_t)max(byte_of(R.g, 3 * j + 2) - mn_l, 0);
             // a, b, c < 256: v_mul_u32_u24 (full rate) instead of the quarter-rate 32-bit multiply
             const uint32_t v[9] = {a, b, c, (uint32_t)__umul24(a, a), (uint32_t)__umul24(a, b), (uint32_t)__umul24(a, c),
                                    (uint32_t)__umul24(b, b), (uint32_t)__umul24(b, c), (uint32_t)__umul24(c, c)};
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
             const double da = (double)a, db = (double)b, dc = (double)c;
 #pragma unroll
             for (int ip = 0; ip < NP; ++ip) {
-                const double pv = ADD ? R.p[ip][j] : -R.p[ip][j];
+                const double pv = R.p[ip][j] * (ADD ? pm : -pm);
                 pf[j][ip][0] += pv; pf[j][ip][1] += da * pv; pf[j][ip][2] += db * pv; pf[j][ip][3] += dc * pv;
             }
         }
@@ -244,8 +253,10 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
         // rows [y - r, y + r]: add y + r, drop y - r - 1 (only rows this block added itself); all conditions uniform
         if (y + r < H) accum(Ra, ADD);
         if (y > y0 && y - r - 1 >= 0) accum(Rs, SUB);
-        if (y + 1 + r < H) load_row(y + 1 + r, Ra);
-        if (y - r >= 0) load_row(y - r, Rs);
+        // always issued (row index clamped into the image; an unused row is simply not accumulated): under a branch the
+        // loaded registers would be copied at its end, i.e. waited for at once
+        load_row(min(y + 1 + r, H - 1), Ra);
+        load_row(max(y - r, 0), Rs);
 
         // ---- horizontal prefix of the nine guide planes
         {
@@ -526,9 +537,9 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
                      (((uintptr_t)P | (uintptr_t)Q | (uintptr_t)AB) % 16 == 0);
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
-    auto slots_of = [&](const void *kernel) {
+    auto slots_of = [&](const void *kernel, int threads = 64) {   // resident blocks on the whole chip
         int per_cu = 8;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0) != hipSuccess || per_cu < 1) per_cu = 8;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess || per_cu < 1) per_cu = 8;
         return (double)per_cu * cus;
     };
     const char *env_split = getenv("UWIP_GF_SPLIT");
