@@ -295,7 +295,6 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
         const double cy = count_of(y - r, y + r, H);
 #pragma unroll
         for (int jj = 0; jj < 4; jj += 2) {
-            double out[2][NP][4];
 #pragma unroll
             for (int j2 = 0; j2 < 2; ++j2) {
                 const int j = jj + j2;
@@ -334,8 +333,6 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
                         const double a2 = (c0 * k02 + c1 * k12 + c2 * k22) * rdet;
                         cs[j][ip][0] += a0; cs[j][ip][1] += a1; cs[j][ip][2] += a2;
                         cs[j][ip][3] += mp - a0 * m0 - a1 * m1 - a2 * m2;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) out[j2][ip][q] = cs[j][ip][q];
                     }
                 }
             }
@@ -346,10 +343,10 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (VEC) {
-                        if (sg.act[jj]) *reinterpret_cast<double2 *>(o + (size_t)q * n) = make_double2(out[0][ip][q], out[1][ip][q]);
+                        if (sg.act[jj]) *reinterpret_cast<double2 *>(o + (size_t)q * n) = make_double2(cs[jj][ip][q], cs[jj + 1][ip][q]);
                     } else {
-                        if (sg.act[jj]) o[(size_t)q * n] = out[0][ip][q];
-                        if (sg.act[jj + 1]) o[(size_t)q * n + 1] = out[1][ip][q];
+                        if (sg.act[jj]) o[(size_t)q * n] = cs[jj][ip][q];
+                        if (sg.act[jj + 1]) o[(size_t)q * n + 1] = cs[jj + 1][ip][q];
                     }
                 }
             }
