@@ -398,13 +398,17 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
         const float inv_w = 1.0f / (float)w;
         // pixel p of the cell -> (x, y); the byte for the NEXT iteration is requested before this one's 17
         // evaluations so its latency hides behind them
+        // (p < 2^16, w < 2^16, rows * step < 2^31: 24-bit multiplies and a 32-bit byte offset are exact and full rate,
+        // where the 32 x 32 and 64-bit forms are quarter rate)
         auto locate = [&](int p, int &x, int &y) {
             int q = (int)(((float)p + 0.5f) * inv_w);
-            int r = p - q * w;
+            int r = p - (int)__umul24((unsigned)q, (unsigned)w);
             if (r < 0) { q--; r += w; }
             if (r >= w) { q++; r -= w; }
             x = ci.x0 + r; y = ci.r0 + q;
         };
+        const uint32_t step24 = (uint32_t)step;
+        auto pix_at = [&](int x, int y) { return (uint32_t)fb[__umul24((unsigned)y, step24) + (unsigned)x]; };
         int xn = 0, yn = 0;
         uint32_t vnext = 0;
         // The 64 pixels of one LDS-atomic instruction are SWEEP_SPREAD apart (lane i of wave w takes pixel
@@ -413,12 +417,12 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
         constexpr int MS = SWEEP_SPREAD / (SWEEP_THREADS / 64);
         auto pix_of = [&](int t) { return (t / MS) * (64 * SWEEP_SPREAD) + (tid & 63) * SWEEP_SPREAD + (tid >> 6) + (SWEEP_THREADS / 64) * (t % MS); };
         int t = 0, p = pix_of(0);
-        if (p < npix) { locate(p, xn, yn); vnext = fb[(size_t)yn * step + xn]; }
+        if (p < npix) { locate(p, xn, yn); vnext = pix_at(xn, yn); }
         for (; p < npix;) {
             const int x = xn, y = yn;
             const uint32_t v = vnext;
             p = pix_of(++t);
-            if (p < npix) { locate(p, xn, yn); vnext = fb[(size_t)yn * step + xn]; }
+            if (p < npix) { locate(p, xn, yn); vnext = pix_at(xn, yn); }
             const float txf = (float)x * inv_tw - 0.5f;
             const float xa = txf - floorf(txf), xa1 = 1.0f - xa;
             const float tyf = (float)y * inv_th - 0.5f;
@@ -753,6 +757,8 @@ UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int resi
     // k_clahe_sweep counts in 16-bit LDS counters: a block must see < 65536 pixels, and its smallest work item is one
     // row of an interpolation cell (at most a tile wide)
     UWIP_REQUIRE(ctx, src->cols <= 65535, "image too wide for the sweep");
+    // ... and addresses a pixel of a frame by a 32-bit byte offset formed with a 24-bit multiply
+    UWIP_REQUIRE(ctx, src->step < (1u << 24) && (uint64_t)src->rows * src->step < (1ull << 32), "frame too large for the sweep");
     const int F = src->frames;
     const size_t out_fs = (size_t)5 * SWEEP_NCL * 256;
     uint32_t *d_out = (uint32_t *)uwip_ws(ctx, "sweep.outhist", sizeof(uint32_t) * out_fs * F);
