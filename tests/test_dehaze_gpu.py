@@ -39,6 +39,21 @@ def test_background_light_vs_oracle(ctx, shape, w):
     assert np.abs(B.cpu().numpy()[0] - Bo).max() <= 1e-15
 
 
+@pytest.mark.parametrize("shape", [(150, 484), (61, 244), (300, 240), (40, 960)])
+def test_fused_window_filter_strip_and_chunk_edges(ctx, shape):
+    """w = 15 with 4-byte aligned rows takes k_winfilter15 (window max + min + frame statistics in one pass): widths
+    that end a few columns into a new 240-column strip, heights that are not a multiple of the row chunk."""
+    img = synth.uw_frame(300 + shape[1], *shape)
+    normI = dz.normalize_input(img)
+    Bo, (i0, i1) = dz.background_light(normI, 15)
+    B, idx = bg.Background_light(ctx, _dev(img), 15, return_index=True)
+    assert idx.cpu().numpy()[0].tolist() == [i0, i1]
+    assert np.abs(B.cpu().numpy()[0] - Bo).max() <= 1e-15
+    t = bg.transmission_map(ctx, _dev(img), _dev(Bo)).cpu().numpy()[0]
+    to = dz.transmission_map(normI, Bo)
+    assert np.abs(t[0] - to[:, :, 0]).max() <= 1e-12 and np.abs(t[1] - to[:, :, 1]).max() <= 1e-12
+
+
 @pytest.mark.parametrize("case", ["a", "b"])
 def test_background_light_vs_reference_golden(ctx, case):
     g = _gold(f"dehaze_{case}.npz")
