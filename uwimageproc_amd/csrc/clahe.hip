@@ -416,13 +416,20 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
         // neighbours of a smooth frame would.
         constexpr int MS = SWEEP_SPREAD / (SWEEP_THREADS / 64);
         auto pix_of = [&](int t) { return (t / MS) * (64 * SWEEP_SPREAD) + (tid & 63) * SWEEP_SPREAD + (tid >> 6) + (SWEEP_THREADS / 64) * (t % MS); };
-        int t = 0, p = pix_of(0);
+        static_assert(MS == 1, "consecutive pixels of a thread are SWEEP_THREADS apart");
+        int p = pix_of(0);
         if (p < npix) { locate(p, xn, yn); vnext = pix_at(xn, yn); }
+        // a thread's next pixel is SWEEP_THREADS further along the cell: step (x, y) instead of dividing again
+        const int dq = SWEEP_THREADS / w, dr = SWEEP_THREADS - dq * w;     // wave-uniform
         for (; p < npix;) {
             const int x = xn, y = yn;
             const uint32_t v = vnext;
-            p = pix_of(++t);
-            if (p < npix) { locate(p, xn, yn); vnext = pix_at(xn, yn); }
+            p += SWEEP_THREADS;
+            if (p < npix) {
+                xn += dr; yn += dq;
+                if (xn >= ci.x1) { xn -= w; yn++; }
+                vnext = pix_at(xn, yn);
+            }
             const float txf = (float)x * inv_tw - 0.5f;
             const float xa = txf - floorf(txf), xa1 = 1.0f - xa;
             const float tyf = (float)y * inv_th - 0.5f;
