@@ -111,9 +111,12 @@ int uwip_imgChannelStretch(uwip_ctx *ctx, const uwip_batch_u8 *img, int channel,
 
 /* The per-letter loop of histretch.cpp:217-254 on BGR frames, in place:
  * for each letter in order, stretch plane numChannel(letter).  Unknown
- * letters are skipped as the reference does; colour-space letters (HSV/HLS/
- * Lab/YCrCb) return UWIP_ERR_UNSUPPORTED (outside the hot path; the
- * reference discards their result). */
+ * letters are skipped as the reference does.  HSV ('H','S','V') and YCrCb
+ * ('Y','C','X') letters do what the reference's code does with them
+ * (SURVEY.md B-3): the stretch lands in a split copy and the image receives
+ * the 8-bit colour round trip cvtColor(BGR2xxx) -> cvtColor(xxx2BGR), applied
+ * in letter order between the BGR letters' stretches.  HLS and Lab letters
+ * return UWIP_ERR_UNSUPPORTED before anything is modified. */
 int uwip_histretch(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi);
 
 /* ---- aclahe (C1-C4) ----------------------------------------------------- */

@@ -147,6 +147,28 @@ ORC_API void orc_imgChannelStretch(uint8_t *data, int rows, int cols, size_t ste
  *     (space 1-4) are out of the hot path (the reference
  *     discards their result); they return 1 here so callers can tell.       */
 /* ------------------------------------------------------------------ */
+/* Colour-space letters as written (histretch.cpp:230-241): the image is converted, the stretch is
+ * applied to a split COPY, cvtColor(dst -> src) converts the unstretched dst back and the merge into dst comes after;
+ * the output is src, i.e. the 8-bit colour round trip of the input.  HSV (space 1) and YCrCb (space 4) are restated
+ * (OpenCV 3.4 color.cpp integer forward / float or integer inverse; parity unpinned); HLS and Lab are not. */
+ORC_API void orc_bgr_to_hsv_px(int b, int g, int r, int *h, int *s, int *v);
+ORC_API void orc_hsv_to_bgr_px(int h, int s, int v, uint8_t out[3]);
+static int orc_descale14(int x) { return (x + (1 << 13)) >> 14; }
+static uint8_t orc_sat8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+ORC_API void orc_ycrcb_roundtrip_px(const uint8_t *p, uint8_t out[3])
+{
+    /* RGB2YCrCb_i<uchar>: coefficients 1868 (B), 9617 (G), 4899 (R), 11682 (Cr), 9241 (Cb), shift 14, delta 128 */
+    const int b = p[0], g = p[1], r = p[2];
+    const int Y = orc_descale14(b * 1868 + g * 9617 + r * 4899);
+    const int Cr = orc_sat8(orc_descale14((r - Y) * 11682 + (128 << 14)));
+    const int Cb = orc_sat8(orc_descale14((b - Y) * 9241 + (128 << 14)));
+    const int Ys = orc_sat8(Y);
+    /* YCrCb2RGB_i<uchar>: 22987 (Cr->R), -11698 (Cr->G), -5636 (Cb->G), 29049 (Cb->B) */
+    out[0] = orc_sat8(Ys + orc_descale14((Cb - 128) * 29049));
+    out[1] = orc_sat8(Ys + orc_descale14((Cb - 128) * -5636 + (Cr - 128) * -11698));
+    out[2] = orc_sat8(Ys + orc_descale14((Cr - 128) * 22987));
+}
+
 ORC_API int orc_histretch_bgr(uint8_t *img, int rows, int cols, size_t step,
                               const char *letters, int lo, int hi)
 {
@@ -154,6 +176,21 @@ ORC_API int orc_histretch_bgr(uint8_t *img, int rows, int cols, size_t step,
     for (const char *c = letters; *c; ++c) {
         int ch = orc_numChannel(*c), sp = orc_numSpace(*c);
         if (sp == -1) continue;
+        if (sp == 1 || sp == 4) {
+            for (int y = 0; y < rows; ++y)
+                for (int x = 0; x < cols; ++x) {
+                    uint8_t *p = img + (size_t)y * step + (size_t)x * 3, o[3];
+                    if (sp == 1) {
+                        int h, s2, v;
+                        orc_bgr_to_hsv_px(p[0], p[1], p[2], &h, &s2, &v);
+                        orc_hsv_to_bgr_px(h, s2, v, o);
+                    } else {
+                        orc_ycrcb_roundtrip_px(p, o);
+                    }
+                    p[0] = o[0]; p[1] = o[1]; p[2] = o[2];
+                }
+            continue;
+        }
         if (sp != 0) { unsupported = 1; continue; }
         orc_imgChannelStretch(img + ch, rows, cols, step, 3, lo, hi);
     }

@@ -111,14 +111,28 @@ def test_stretch_lut_stage_tap(ctx, orc):
         assert bounds[c].tolist() == [lo, hi]
 
 
+@pytest.mark.parametrize("letters", ["V", "H", "Y", "RHG", "BCX", "SVR", "YH"])
+@pytest.mark.parametrize("shape", [(48, 64), (37, 53)])
+def test_colour_space_letters_as_written(ctx, orc, letters, shape):
+    """HSV / YCrCb letters as the reference executes them: the 8-bit colour round trip of the image,
+    interleaved in order with the BGR letters' stretches."""
+    img = synth.uw_frame(11, *shape)
+    t = _dev(img)
+    pp.histretch(ctx, t, letters)
+    exp, rc = orc.histretch(img, letters)
+    assert rc == 0
+    assert np.array_equal(t.cpu().numpy(), exp)
+
+
 def test_empty_and_errors(ctx):
     import uwimageproc_amd as uw
     e = torch.zeros((0, 8, 3), dtype=torch.uint8, device="cuda")
     pp.histretch(ctx, e, "RGB")            # empty input is a no-op
     img = _dev(synth.uw_frame(1, 16, 16))
+    before = img.clone()
     with pytest.raises(uw.UwipError) as ei:
-        pp.histretch(ctx, img, "V")        # colour-space letters are outside the hot path
-    assert ei.value.code == 3
+        pp.histretch(ctx, img, "RL")       # HLS / Lab letters are not implemented: refused before anything is touched
+    assert ei.value.code == 3 and torch.equal(img, before)
     with pytest.raises(uw.UwipError):
         pp.imgChannelStretch(ctx, img, None, 2, 98, channel=5)
 

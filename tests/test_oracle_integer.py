@@ -99,9 +99,16 @@ def test_histretch_letter_quirks(orc):
     twice, _ = orc.histretch(img, "GG")
     again, _ = orc.histretch(once, "G")
     assert np.array_equal(twice, again)
-    # colour-space letters are flagged (outside the hot path)
-    _, rc = orc.histretch(img, "V")
+    # HLS / Lab letters are flagged (not restated); HSV / YCrCb letters are the colour round trip of the image (B-3)
+    _, rc = orc.histretch(img, "L")
     assert rc == 1
+    rt, rc = orc.histretch(img, "V")
+    assert rc == 0 and np.abs(rt.astype(int) - img.astype(int)).max() <= 4
+    grey = np.repeat(np.arange(0, 256, 8, dtype=np.uint8).reshape(4, 8, 1), 3, axis=2)   # S = 0: exact round trip
+    assert np.array_equal(orc.histretch(grey, "H")[0], grey) and np.array_equal(orc.histretch(grey, "Y")[0], grey)
+    # YCrCb known answer: pure blue (255, 0, 0) -> Y = 29, Cr = 107, Cb = 255 -> back to (254, 0, 0)
+    blue = np.zeros((1, 1, 3), np.uint8); blue[0, 0, 0] = 255
+    assert orc.histretch(blue, "C")[0][0, 0].tolist() == [254, 0, 0]
 
 
 # ---------------------------------------------------------------- CLAHE ----

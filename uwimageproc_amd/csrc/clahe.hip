@@ -914,6 +914,7 @@ __device__ __forceinline__ void hsv_replace_px(int b, int g, int r, int vnew, co
                                                const int *__restrict__ hdiv, uint32_t &ob8, uint32_t &og8, uint32_t &or8)
 {
     const int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+    if (vnew < 0) vnew = v;      // plain BGR -> HSV -> BGR round trip
     const int diff = v - vmin;
     const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
     const int sat = (diff * sdiv[v] + (1 << 11)) >> 12;
@@ -957,13 +958,13 @@ __global__ __launch_bounds__(256) void k_hsv_replace_v(const uint8_t *__restrict
 {
     const int f = blockIdx.z, y = blockIdx.y;
     const uint8_t *s = src + (size_t)f * sfs + (size_t)y * sstep;
-    const uint8_t *vn = vnew + (size_t)f * vfs + (size_t)y * vstep;
+    const uint8_t *vn = vnew ? vnew + (size_t)f * vfs + (size_t)y * vstep : nullptr;   // null: keep the pixel's own V
     uint8_t *d = dst + (size_t)f * dfs + (size_t)y * dstep;
     if (VEC) {
         for (int x4 = blockIdx.x * 256 + threadIdx.x; x4 < cols / 4; x4 += gridDim.x * 256) {
             const uint32_t *sp = reinterpret_cast<const uint32_t *>(s) + 3 * x4;
             const uint32_t w[3] = {sp[0], sp[1], sp[2]};
-            const uint32_t vv = reinterpret_cast<const uint32_t *>(vn)[x4];
+            const uint32_t vv = vn ? reinterpret_cast<const uint32_t *>(vn)[x4] : 0u;
             uint32_t o[3] = {0u, 0u, 0u};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -971,7 +972,7 @@ __global__ __launch_bounds__(256) void k_hsv_replace_v(const uint8_t *__restrict
                 const int b = (w[k >> 2] >> ((k & 3) * 8)) & 255, g = (w[(k + 1) >> 2] >> (((k + 1) & 3) * 8)) & 255,
                           r = (w[(k + 2) >> 2] >> (((k + 2) & 3) * 8)) & 255;
                 uint32_t ob, og, orr;
-                hsv_replace_px(b, g, r, (int)((vv >> (8 * j)) & 255u), sdiv, hdiv, ob, og, orr);
+                hsv_replace_px(b, g, r, vn ? (int)((vv >> (8 * j)) & 255u) : -1, sdiv, hdiv, ob, og, orr);
                 o[k >> 2] |= ob << ((k & 3) * 8);
                 o[(k + 1) >> 2] |= og << (((k + 1) & 3) * 8);
                 o[(k + 2) >> 2] |= orr << (((k + 2) & 3) * 8);
@@ -982,7 +983,7 @@ __global__ __launch_bounds__(256) void k_hsv_replace_v(const uint8_t *__restrict
     } else {
         for (int x = blockIdx.x * 256 + threadIdx.x; x < cols; x += gridDim.x * 256) {
             uint32_t ob, og, orr;
-            hsv_replace_px(s[3 * x], s[3 * x + 1], s[3 * x + 2], vn[x], sdiv, hdiv, ob, og, orr);
+            hsv_replace_px(s[3 * x], s[3 * x + 1], s[3 * x + 2], vn ? (int)vn[x] : -1, sdiv, hdiv, ob, og, orr);
             d[3 * x] = (uint8_t)ob; d[3 * x + 1] = (uint8_t)og; d[3 * x + 2] = (uint8_t)orr;
         }
     }
@@ -1027,6 +1028,28 @@ UWIP_API int uwip_hsv_replace_v(uwip_ctx *ctx, const uwip_batch_u8 *bgr, const u
         k_hsv_replace_v<false><<<grid, 256, 0, ctx->stream>>>(
             (const uint8_t *)bgr->data, bgr->step, bgr->frame_stride, (const uint8_t *)v_new->data, v_new->step, v_new->frame_stride,
             (uint8_t *)bgr_out->data, bgr_out->step, bgr_out->frame_stride, bgr->rows, bgr->cols, tabs, tabs + 256);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}
+
+// cvtColor(BGR2HSV) followed by cvtColor(HSV2BGR), 8-bit, in place: what an HSV letter of histretch leaves in the image
+// (histretch.cpp:232-238).
+int uwip_hsv_roundtrip(uwip_ctx *ctx, const uwip_batch_u8 *img)
+{
+    if (uwip_batch_empty(img)) return UWIP_OK;
+    UWIP_REQUIRE(ctx, img->rows <= 65535 && img->frames <= 65535, "too many rows/frames for one launch");
+    const int *tabs = hsv_tables(ctx);
+    if (!tabs) return UWIP_ERR_NOMEM;
+    uwip_kscope ks(ctx, "k_hsv_replace_v");
+    const bool vec = img->cols % 4 == 0 && ((uintptr_t)img->data | img->step | img->frame_stride) % 4 == 0;
+    const dim3 grid(uwip_cdiv(vec ? img->cols / 4 : img->cols, 256), (unsigned)img->rows, (unsigned)img->frames);
+    uint8_t *d = (uint8_t *)img->data;
+    if (vec)
+        k_hsv_replace_v<true><<<grid, 256, 0, ctx->stream>>>(d, img->step, img->frame_stride, nullptr, 0, 0, d, img->step, img->frame_stride,
+                                                             img->rows, img->cols, tabs, tabs + 256);
+    else
+        k_hsv_replace_v<false><<<grid, 256, 0, ctx->stream>>>(d, img->step, img->frame_stride, nullptr, 0, 0, d, img->step, img->frame_stride,
+                                                              img->rows, img->cols, tabs, tabs + 256);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }

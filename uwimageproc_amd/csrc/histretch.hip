@@ -432,20 +432,71 @@ UWIP_API int uwip_imgChannelStretch(uwip_ctx *ctx, const uwip_batch_u8 *img, int
     return stretch_planes(ctx, img, L, lo, hi);
 }
 
+namespace {
+// cvtColor(BGR2YCrCb) followed by cvtColor(YCrCb2BGR), 8-bit, in place (OpenCV 3.4 RGB2YCrCb_i / YCrCb2RGB_i: shift 14,
+// delta 128; forward 1868 / 9617 / 4899, 11682, 9241; inverse 22987, -11698, -5636, 29049).  parity unpinned.
+__device__ __forceinline__ int descale14(int x) { return (x + (1 << 13)) >> 14; }
+__device__ __forceinline__ int sat8(int x) { return min(max(x, 0), 255); }
+__global__ __launch_bounds__(256) void k_ycrcb_roundtrip(uint8_t *__restrict__ img, size_t step, size_t fs, int rows, int cols)
+{
+    const int f = blockIdx.z, y = blockIdx.y;
+    uint8_t *row = img + (size_t)f * fs + (size_t)y * step;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < cols; x += gridDim.x * 256) {
+        const int b = row[3 * x], g = row[3 * x + 1], r = row[3 * x + 2];
+        const int Y = descale14(b * 1868 + g * 9617 + r * 4899);
+        const int Cr = sat8(descale14((r - Y) * 11682 + (128 << 14)));
+        const int Cb = sat8(descale14((b - Y) * 9241 + (128 << 14)));
+        const int Ys = sat8(Y);
+        row[3 * x] = (uint8_t)sat8(Ys + descale14((Cb - 128) * 29049));
+        row[3 * x + 1] = (uint8_t)sat8(Ys + descale14((Cb - 128) * -5636 + (Cr - 128) * -11698));
+        row[3 * x + 2] = (uint8_t)sat8(Ys + descale14((Cr - 128) * 22987));
+    }
+}
+}  // namespace
+
 UWIP_API int uwip_histretch(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi)
 {
     int rc = uwip_check_batch(ctx, img, 3);
     if (rc) return rc;
     UWIP_REQUIRE(ctx, letters != nullptr, "null letters");
+    // validate first: HLS / Lab letters are refused before anything is touched
+    for (const char *c = letters; *c; ++c) {
+        const int sp = uwip_numSpace(*c);
+        if (sp == 2 || sp == 3)
+            return ctx->fail(UWIP_ERR_UNSUPPORTED, "HLS / Lab letters of histretch are not implemented (HSV and YCrCb are)");
+    }
+    // Runs of BGR letters are composed into one LUT pass; an HSV / YCrCb letter is, as written in the reference
+    // (histretch.cpp:230-241), the colour round trip of the image: the stretch goes to a split copy and
+    // cvtColor(dst -> src) converts the unstretched planes back before the merge.
     LetterList L{};
     L.n = 0;
+    auto flush = [&]() -> int {
+        if (L.n == 0) return UWIP_OK;
+        const int r2 = stretch_planes(ctx, img, L, lo, hi);
+        L.n = 0;
+        return r2;
+    };
     for (const char *c = letters; *c; ++c) {
         const int sp = uwip_numSpace(*c);
         if (sp == -1) continue;                        // "not recognized, skipping" (histretch.cpp:252)
-        if (sp != 0)
-            return ctx->fail(UWIP_ERR_UNSUPPORTED, "colour-space letters (HSV/HLS/Lab/YCrCb) are outside the hot path");
-        UWIP_REQUIRE(ctx, L.n < 64, "more than 64 letters");
-        L.plane[L.n++] = (int8_t)uwip_numChannel(*c);
+        if (sp == 0) {
+            if (L.n == 64) { rc = flush(); if (rc) return rc; }
+            L.plane[L.n++] = (int8_t)uwip_numChannel(*c);
+            continue;
+        }
+        rc = flush();
+        if (rc) return rc;
+        if (uwip_batch_empty(img)) continue;
+        if (sp == 1) {
+            rc = uwip_hsv_roundtrip(ctx, img);
+            if (rc) return rc;
+        } else {
+            UWIP_REQUIRE(ctx, img->rows <= 65535 && img->frames <= 65535, "too many rows/frames for one launch");
+            uwip_kscope ks(ctx, "k_ycrcb_roundtrip");
+            k_ycrcb_roundtrip<<<dim3(uwip_cdiv(img->cols, 256), (unsigned)img->rows, (unsigned)img->frames), 256, 0, ctx->stream>>>(
+                (uint8_t *)img->data, img->step, img->frame_stride, img->rows, img->cols);
+            UWIP_HIP(ctx, hipGetLastError());
+        }
     }
-    return stretch_planes(ctx, img, L, lo, hi);
+    return flush();
 }

@@ -58,6 +58,8 @@ void *uwip_host_ws(uwip_ctx *ctx, const char *name, size_t bytes);  // pinned ho
 const void *uwip_table_find(uwip_ctx *ctx, const std::string &key, size_t *bytes);
 const void *uwip_table_put(uwip_ctx *ctx, const std::string &key, const void *host, size_t bytes);
 int uwip_prof_flush(uwip_ctx *ctx);
+// clahe.hip: in-place 8-bit BGR -> HSV -> BGR (an HSV letter of histretch)
+int uwip_hsv_roundtrip(uwip_ctx *ctx, const uwip_batch_u8 *img);
 // winfilter15.hip: 15x15 window max and/or min of interleaved 3-channel u8 frames -> planar [F][3][H][W]
 bool uwip_winfilter15_ok(const uint8_t *img, size_t step, size_t fs, int H, int W, int w);
 // stats (optional, both filters only): stats[f*stride + {0..3}] = min, max of all channels, min, max of channel 2,
