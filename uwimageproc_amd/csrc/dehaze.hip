@@ -255,6 +255,10 @@ __global__ void k_bglight_final(const double *__restrict__ pval, const int *__re
     }
     int *s = si + (size_t)f * SI_COUNT;
     double *d = sc + (size_t)f * SC_COUNT;
+    // A constant frame (max == min) normalises to 0/0 = NaN everywhere: no difference ever compares below the running
+    // minimum and the indices keep their initial value.  numpy's argmin returns the first NaN, i.e. pixel 0.
+    if (i0 == 0x7fffffff) i0 = 0;
+    if (i1 == 0x7fffffff) i1 = 0;
     s[SI_IDX0] = i0; s[SI_IDX1] = i1;
     const int mn = s[SI_MN], mx = s[SI_MX];
     d[SC_MN] = mn; d[SC_MX] = mx;
