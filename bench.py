@@ -194,6 +194,13 @@ def main():
             roof = {"bound": "hbm", "kernel": "k_clahe_apply", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_clahe_apply", H, W, Fs * nprof / cnt), "avg_launch_ms": avg_ms,
                     "algorithmic_bytes_per_launch": per_launch_bytes}
+        # for orientation: the kernels that actually dominate the step (the sweep is VALU-issue bound, the guided-filter
+        # kernels HBM / VALU bound: DESIGN.md section 5, profiles/r01_sq_counters.txt)
+        if roof is not None and kernels:
+            tot = sum(v["ms_per_step"] for v in kernels.values())
+            top = sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])[:3]
+            roof["step_kernel_ms"] = tot
+            roof["largest_kernels"] = [{"kernel": k, "ms_per_step": v["ms_per_step"], "share": v["ms_per_step"] / tot} for k, v in top]
 
     if rank == 0:
         cpu = None
