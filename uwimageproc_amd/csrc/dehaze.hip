@@ -597,11 +597,12 @@ struct DzBufs {
 // guided filter with a normalised-u8 guide: P [F][np] planes -> Q [F][np] planes
 // The guided filter itself lives in guided_filter_ws.hip (wave-strip kernels).
 int guided_filter_u8(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs, const int *gnorm, int gstride,
-                     const double *P, double *Q, double *AB, int F, int np, int H, int W, int r, double eps)
+                     const double *P, double *Q, double *AB, int F, int np, int H, int W, int r, double eps,
+                     const uwip_gf_pu8 *pu8 = nullptr)
 {
     UWIP_REQUIRE(ctx, H >= 2 * r + 1 && W >= 2 * r + 1, "guided filter needs rows, cols >= 2r+1 (guidedfilter.py:39-41)");
     UWIP_REQUIRE(ctx, r <= 96, "guided filter radius > 96 is not supported");
-    return uwip_gf_wave_strip(ctx, guide, step, fs, gnorm, gstride, P, Q, AB, F, np, H, W, r, eps);
+    return uwip_gf_wave_strip(ctx, guide, step, fs, gnorm, gstride, P, Q, AB, F, np, H, W, r, eps, pu8);
 }
 
 int alloc_bufs(uwip_ctx *ctx, int F, int H, int W, DzBufs *b)
@@ -774,10 +775,21 @@ UWIP_API int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batc
     const uint8_t *img = (const uint8_t *)in->data;
     rc = run_bglight(ctx, in, w, b, d_B_inject, w == 15);
     if (rc) return rc;
-    rc = run_transmission(ctx, in, b, tmin, nullptr);
-    if (rc) return rc;
-    rc = guided_filter_u8(ctx, img, in->step, in->frame_stride, b.si, SI_COUNT, b.P, b.Q, b.AB, F, 2, H, W, r, eps);
-    if (rc) return rc;
+    if (b.u8min && uwip_gf_pu8_ok(img, in->step, in->frame_stride, b.u8min, 2, W, r)) {
+        // the transmission is a per-frame function of the 8-bit window-minimum planes: the guided filter derives it on
+        // the fly (uwip_gf_pu8) and the float64 P planes of k_transmission are never written
+        uwip_gf_pu8 pu8;
+        pu8.planes = b.u8min; pu8.nplanes = 3;
+        pu8.sc = b.sc; pu8.sc_stride = SC_COUNT; pu8.b_off = SC_B0;
+        pu8.tmin = tmin; pu8.w = 15; pu8.pad = 7;                     // refined_t drops w (BGDehaze.py:52, B-10)
+        rc = guided_filter_u8(ctx, img, in->step, in->frame_stride, b.si, SI_COUNT, nullptr, b.Q, b.AB, F, 2, H, W, r, eps, &pu8);
+        if (rc) return rc;
+    } else {
+        rc = run_transmission(ctx, in, b, tmin, nullptr);
+        if (rc) return rc;
+        rc = guided_filter_u8(ctx, img, in->step, in->frame_stride, b.si, SI_COUNT, b.P, b.Q, b.AB, F, 2, H, W, r, eps);
+        if (rc) return rc;
+    }
     if (d_refined_t)
         UWIP_HIP(ctx, hipMemcpyAsync(d_refined_t, b.Q, sizeof(double) * 2 * n * F, hipMemcpyDeviceToDevice, ctx->stream));
     {

@@ -120,23 +120,35 @@ __device__ __forceinline__ double fast_rcp(double d)
 __device__ __forceinline__ double count_of(int lo, int hi, int n) { return (double)(min(hi, n - 1) - max(lo, 0) + 1); }
 
 // ---- a, b ---------------------------------------------------------------------------------------------
-template <int NP>
+template <int NP, bool PU8>
 struct SolveRow {
     u32x3 g;            // 4 columns x 3 bytes of the guide
     double p[NP][4];
 };
+template <int NP>
+struct SolveRow<NP, true> {
+    u32x3 g;
+    uint32_t m[NP];     // 4 columns x 1 byte per p plane: p = table[byte]
+};
 
-template <int NP, bool VEC>
+// PU8 (bgdehaze's transmission, needs VEC): p is not read as float64 planes but derived on the fly -- plane ip of frame f
+// is  p = max(1 - normv(m) / B_ip, tmin)  of the 8-bit window-minimum plane m (BGDehaze.py:28-37, :52), i.e. a 256-entry
+// per-frame table, with p = 1 where the w x w window leaves the image (zero padding, :32).  Same values as
+// k_transmission writes, 1 byte instead of 8 per sample and no P planes in HBM at all.
+template <int NP, bool VEC, bool PU8>
 __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ guide, size_t step, size_t fs,
                                                     const int *__restrict__ gnorm, int gnorm_stride,
                                                     const double *__restrict__ P /*[F][NP][H][W]*/,
                                                     double *__restrict__ AB /*[F*NP][4][H][W]: column prefix sums of a, b*/,
-                                                    int H, int W, int r, double eps, int TS, int rpc, int fdiv, uint3 nb)
+                                                    int H, int W, int r, double eps, int TS, int rpc, int fdiv, uint3 nb,
+                                                    uwip_gf_pu8 pu8)
 {
 #pragma clang fp contract(fast)
+    static_assert(!PU8 || VEC, "the 8-bit p source needs the aligned path");
     __shared__ uint4 s_u4[2 * 4 * 64];
     __shared__ uint32_t s_u1[4 * 64];
     __shared__ double2 s_d2[NP * 2 * 4 * 64];
+    __shared__ double s_ptab[PU8 ? NP * 256 : 1];
     unsigned bx, by, bz;
     if (!xcd_decode(nb.x, nb.y, nb.z, bx, by, bz)) return;
     StripGeom sg;
@@ -148,6 +160,23 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
     const uint32_t fillw = (uint32_t)mn * 0x01010101u;
     const uint8_t *gf = guide + (size_t)f * fs;
     const double *pin = P + (size_t)zg * NP * n;
+    double p_out = 0.0;         // PU8: p where the window leaves the image
+    bool cin[4] = {true, true, true, true};
+    if (PU8) {
+        for (int idx = l; idx < NP * 256; idx += 64) {
+            const int ip = idx >> 8, v = idx & 255;
+            const double B = pu8.sc[(size_t)f * pu8.sc_stride + pu8.b_off + ip];
+            const double q = ((double)(v - mn) / (double)(mx - mn)) / B;
+            s_ptab[idx] = fmax(1.0 - q, pu8.tmin);
+        }
+        p_out = fmax(1.0 - 0.0, pu8.tmin);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int x = sg.x0 + j;
+            cin[j] = (x - pu8.pad >= 0) && (x - pu8.pad + pu8.w <= W);
+        }
+        wave_lds_fence();
+    }
 
     uint32_t gi[4][9];
     double pf[4][NP][4];
@@ -165,21 +194,31 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
 
     // A row buffer is cleared ONCE (guide bytes = mn, p = 0: contributes nothing); load_row then only overwrites the
     // lanes / columns that are inside the image, so out-of-image columns stay neutral without a per-row refill.
-    auto clear_row = [&](SolveRow<NP> &R) {
+    auto clear_row = [&](SolveRow<NP, PU8> &R) {
         R.g = u32x3{fillw, fillw, fillw};
+        if constexpr (PU8) {
 #pragma unroll
-        for (int ip = 0; ip < NP; ++ip) R.p[ip][0] = R.p[ip][1] = R.p[ip][2] = R.p[ip][3] = 0.0;
+            for (int ip = 0; ip < NP; ++ip) R.m[ip] = 0u;
+        } else {
+#pragma unroll
+            for (int ip = 0; ip < NP; ++ip) R.p[ip][0] = R.p[ip][1] = R.p[ip][2] = R.p[ip][3] = 0.0;
+        }
     };
     // per-lane bases; the row offsets below are wave-uniform (scalar) products
     const uint8_t *g_lane = gf + (size_t)(sg.in[0] ? sg.x0 : 0) * 3;
     const double *p_lane = pin + (sg.in[0] ? sg.x0 : 0);
+    const uint8_t *m_lane = PU8 ? pu8.planes + (size_t)f * pu8.nplanes * n + (sg.in[0] ? sg.x0 : 0) : nullptr;
     // VEC: every lane loads unconditionally (lanes outside the image read the row's first columns and are neutralised in
     // accum by mn_l / pm): a load under a lane mask has to be merged with the register's old contents, and that merge
     // sits right behind the load -- it made every row wait for its own prefetch.
     const int mn_l = (VEC && !sg.in[0]) ? 255 : mn;
     const double pm = (VEC && !sg.in[0]) ? 0.0 : 1.0;
-    auto load_row = [&](int yy, SolveRow<NP> &R) {   // yy must be a row of the image
-        if (VEC) {
+    auto load_row = [&](int yy, SolveRow<NP, PU8> &R) {   // yy must be a row of the image
+        if constexpr (PU8) {
+            R.g = *reinterpret_cast<const u32x3 *>(g_lane + (size_t)yy * step);
+#pragma unroll
+            for (int ip = 0; ip < NP; ++ip) R.m[ip] = *reinterpret_cast<const uint32_t *>(m_lane + ((size_t)ip * H + yy) * W);
+        } else if constexpr (VEC) {
             {
                 const uint32_t *q = reinterpret_cast<const uint32_t *>(g_lane + (size_t)yy * step);
                 R.g = *reinterpret_cast<const u32x3 *>(q);
@@ -205,8 +244,9 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
             for (int w = 0; w < 3; ++w) R.g[w] = b[4 * w] | (b[4 * w + 1] << 8) | (b[4 * w + 2] << 16) | (b[4 * w + 3] << 24);
         }
     };
-    auto accum = [&](const SolveRow<NP> &R, auto add_tag) {
+    auto accum = [&](const SolveRow<NP, PU8> &R, auto add_tag, int yy) {
         constexpr bool ADD = decltype(add_tag)::value;
+        const bool rin = PU8 && (yy - pu8.pad >= 0) && (yy - pu8.pad + pu8.w <= H);   // uniform
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t a = (uint32_t)max(byte_of(R.g, 3 * j) - mn_l, 0), b = (uint32_t)max(byte_of(R.g, 3 * j + 1) - mn_l, 0),
@@ -219,7 +259,10 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
             const double da = (double)a, db = (double)b, dc = (double)c;
 #pragma unroll
             for (int ip = 0; ip < NP; ++ip) {
-                const double pv = R.p[ip][j] * (ADD ? pm : -pm);
+                double pv;
+                if constexpr (PU8) pv = (rin && cin[j]) ? s_ptab[ip * 256 + ((R.m[ip] >> (8 * j)) & 255u)] : p_out;
+                else pv = R.p[ip][j];
+                pv *= (ADD ? pm : -pm);
                 pf[j][ip][0] += pv; pf[j][ip][1] += da * pv; pf[j][ip][2] += db * pv; pf[j][ip][3] += dc * pv;
             }
         }
@@ -233,26 +276,26 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
     int v = max(y0 - r, 0);
     const int wend = min(y0 + r, H);   // first row that belongs to the steady loop
     {
-        SolveRow<NP> R0, R1, R2, R3;
+        SolveRow<NP, PU8> R0, R1, R2, R3;
         clear_row(R0); clear_row(R1); clear_row(R2); clear_row(R3);
         for (; v < wend; v += 4) {
             load_row(v, R0);
             if (v + 1 < wend) load_row(v + 1, R1);
             if (v + 2 < wend) load_row(v + 2, R2);
             if (v + 3 < wend) load_row(v + 3, R3);
-            accum(R0, ADD);
-            if (v + 1 < wend) accum(R1, ADD);
-            if (v + 2 < wend) accum(R2, ADD);
-            if (v + 3 < wend) accum(R3, ADD);
+            accum(R0, ADD, v);
+            if (v + 1 < wend) accum(R1, ADD, v + 1);
+            if (v + 2 < wend) accum(R2, ADD, v + 2);
+            if (v + 3 < wend) accum(R3, ADD, v + 3);
         }
     }
-    SolveRow<NP> Ra, Rs;
+    SolveRow<NP, PU8> Ra, Rs;
     clear_row(Ra); clear_row(Rs);
     if (y0 + r < H) load_row(y0 + r, Ra);
     for (int y = y0; y < y1; ++y) {
         // rows [y - r, y + r]: add y + r, drop y - r - 1 (only rows this block added itself); all conditions uniform
-        if (y + r < H) accum(Ra, ADD);
-        if (y > y0 && y - r - 1 >= 0) accum(Rs, SUB);
+        if (y + r < H) accum(Ra, ADD, y + r);
+        if (y > y0 && y - r - 1 >= 0) accum(Rs, SUB, y - r - 1);
         // always issued (row index clamped into the image; an unused row is simply not accumulated): under a branch the
         // loaded registers would be copied at its end, i.e. waited for at once
         load_row(min(y + 1 + r, H - 1), Ra);
@@ -519,8 +562,15 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
 
 // Launches the two kernels.  guide: 3-channel u8 frames; gnorm[f*gstride + {0,1}] = the frame's min / max guide
 // value; P [F][np][H][W] -> Q [F][np][H][W]; AB [F*np][4][H][W] scratch (column prefix sums of a, b).
+bool uwip_gf_pu8_ok(const uint8_t *guide, size_t step, size_t fs, const uint8_t *planes, int np, int W, int r)
+{
+    return np == 2 && planes && (W % 4 == 0) && (r % 4 == 0) && (step % 4 == 0) && (fs % 4 == 0) && (((uintptr_t)guide) % 4 == 0) &&
+           (((uintptr_t)planes) % 4 == 0);
+}
+
 int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs, const int *gnorm, int gstride,
-                       const double *P, double *Q, double *AB, int F, int np, int H, int W, int r, double eps)
+                       const double *P, double *Q, double *AB, int F, int np, int H, int W, int r, double eps,
+                       const uwip_gf_pu8 *pu8)
 {
     UWIP_REQUIRE(ctx, np == 1 || np == 2, "np must be 1 or 2");
     UWIP_REQUIRE(ctx, r >= 1 && 2 * r <= 192, "radius out of range for the 256-column strip");
@@ -532,6 +582,8 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
     // four adjacent columns of a lane are one aligned vector access when everything is a multiple of 4
     const bool vec = (W % 4 == 0) && (r % 4 == 0) && (step % 4 == 0) && (fs % 4 == 0) && (((uintptr_t)guide) % 4 == 0) &&
                      (((uintptr_t)P | (uintptr_t)Q | (uintptr_t)AB) % 16 == 0);
+    if (pu8) UWIP_REQUIRE(ctx, vec && uwip_gf_pu8_ok(guide, step, fs, pu8->planes, np, W, r) && pu8->sc, "8-bit p source: unsupported geometry");
+    UWIP_REQUIRE(ctx, pu8 || P, "null p planes");
     int cus = 256;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) != hipSuccess || cus < 1) cus = 256;
     auto slots_of = [&](const void *kernel, int threads = 64) {   // resident blocks on the whole chip
@@ -540,11 +592,12 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
         return (double)per_cu * cus;
     };
     const char *env_split = getenv("UWIP_GF_SPLIT");
-    const bool split = np == 2 && env_split && atoi(env_split) > 0;   // two one-plane solves instead of a fused one
+    const bool split = !pu8 && np == 2 && env_split && atoi(env_split) > 0;   // two one-plane solves instead of a fused one
     const int knp = split ? 1 : np;
     const unsigned zs = (unsigned)F * (np / knp);
-    const void *ksolve = knp == 2 ? (vec ? (const void *)k_gf_ws_solve<2, true> : (const void *)k_gf_ws_solve<2, false>)
-                                  : (vec ? (const void *)k_gf_ws_solve<1, true> : (const void *)k_gf_ws_solve<1, false>);
+    const void *ksolve = pu8 ? (const void *)k_gf_ws_solve<2, true, true>
+                       : knp == 2 ? (vec ? (const void *)k_gf_ws_solve<2, true, false> : (const void *)k_gf_ws_solve<2, false, false>)
+                                  : (vec ? (const void *)k_gf_ws_solve<1, true, false> : (const void *)k_gf_ws_solve<1, false, false>);
     // solve: every row chunk re-reads 2r warm-up rows, so use as few chunks as keep the chip full, preferring a whole
     // number of "rounds" of resident waves.  A chunk is at least 2r+1 rows (k_gf_ws_final relies on it).
     int c = 1;
@@ -570,12 +623,15 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
         const unsigned grid = 8u * ((nb.x * nb.y * nb.z + 7u) / 8u);
         uwip_kscope ks(ctx, "k_gf_ws_solve");
         const int fdiv = np / knp;
-        if (knp == 2) {
-            if (vec) k_gf_ws_solve<2, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb);
-            else k_gf_ws_solve<2, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb);
+        const uwip_gf_pu8 none{};
+        if (pu8) {
+            k_gf_ws_solve<2, true, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, *pu8);
+        } else if (knp == 2) {
+            if (vec) k_gf_ws_solve<2, true, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none);
+            else k_gf_ws_solve<2, false, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none);
         } else {
-            if (vec) k_gf_ws_solve<1, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb);
-            else k_gf_ws_solve<1, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb);
+            if (vec) k_gf_ws_solve<1, true, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none);
+            else k_gf_ws_solve<1, false, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none);
         }
     }
     {
