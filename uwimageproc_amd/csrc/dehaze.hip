@@ -340,6 +340,26 @@ __global__ void k_recover_final(const double *__restrict__ part, int nb, double 
     s[SC_JMIN0] = a; s[SC_JMAX0] = b; s[SC_JMIN1] = c; s[SC_JMAX1] = d; s[SC_MEANR] = e / npix;
 }
 
+// Scene recovery fused into the guided filter (uwip_gf_recover): per-block (min, max) pairs of J for both planes, and the
+// mean of the normalised red channel from the exact integer sum of the red bytes:
+// mean((v - mn) / (mx - mn)) = (sum(v) - n mn) / (mx - mn) / n  (one rounding of an exact integer instead of n).
+__global__ void k_recover_final2(const double *__restrict__ jpart, int nb, const unsigned long long *__restrict__ redsum,
+                                 const int *__restrict__ si, double *__restrict__ sc, double npix)
+{
+    const int f = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    double a = 1e300, b = -1e300, c = 1e300, d = -1e300;
+    for (int k = 0; k < nb; ++k) {
+        const double *p0 = jpart + ((size_t)(2 * f) * nb + k) * 2, *p1 = jpart + ((size_t)(2 * f + 1) * nb + k) * 2;
+        a = fmin(a, p0[0]); b = fmax(b, p0[1]); c = fmin(c, p1[0]); d = fmax(d, p1[1]);
+    }
+    const int mn = si[(size_t)f * SI_COUNT + SI_MN], mx = si[(size_t)f * SI_COUNT + SI_MX];
+    const double sumr = (double)((long long)redsum[f] - (long long)npix * mn);
+    double *s = sc + (size_t)f * SC_COUNT;
+    s[SC_JMIN0] = a; s[SC_JMAX0] = b; s[SC_JMIN1] = c; s[SC_JMAX1] = d;
+    s[SC_MEANR] = sumr / (double)(mx - mn) / npix;
+}
+
 // partial sums for the means of the min-max normalised J (BGDehaze.py:54,56,61).  J stays as it is in Q: every consumer
 // applies (J - min) / (max - min) itself (restored_px), which saves rewriting two float64 planes.
 __global__ __launch_bounds__(256) void k_normJ(const double *__restrict__ Q, const double *__restrict__ sc, int H, int W,
@@ -592,17 +612,18 @@ struct DzBufs {
     uint8_t *u8planes;       // [F][3][H][W] window max/min
     double *P, *AB, *Q;
     uint8_t *u8min = nullptr;   // window-min planes when the fused 15x15 kernel produced them already
+    unsigned long long *redsum = nullptr;   // ... and the exact per-frame sum of the red bytes
 };
 
 // guided filter with a normalised-u8 guide: P [F][np] planes -> Q [F][np] planes
 // The guided filter itself lives in guided_filter_ws.hip (wave-strip kernels).
 int guided_filter_u8(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs, const int *gnorm, int gstride,
                      const double *P, double *Q, double *AB, int F, int np, int H, int W, int r, double eps,
-                     const uwip_gf_pu8 *pu8 = nullptr)
+                     const uwip_gf_pu8 *pu8 = nullptr, uwip_gf_recover *rec = nullptr)
 {
     UWIP_REQUIRE(ctx, H >= 2 * r + 1 && W >= 2 * r + 1, "guided filter needs rows, cols >= 2r+1 (guidedfilter.py:39-41)");
     UWIP_REQUIRE(ctx, r <= 96, "guided filter radius > 96 is not supported");
-    return uwip_gf_wave_strip(ctx, guide, step, fs, gnorm, gstride, P, Q, AB, F, np, H, W, r, eps, pu8);
+    return uwip_gf_wave_strip(ctx, guide, step, fs, gnorm, gstride, P, Q, AB, F, np, H, W, r, eps, pu8, rec);
 }
 
 int alloc_bufs(uwip_ctx *ctx, int F, int H, int W, DzBufs *b)
@@ -644,6 +665,7 @@ int run_bglight(uwip_ctx *ctx, const uwip_batch_u8 *in, int w, DzBufs &b, const 
     }
     const int pad = w / 2;
     b.u8min = nullptr;
+    b.redsum = nullptr;
     if (fast15) {
         // one pass for the window maximum and (when the transmission follows) the window minimum
         uint8_t *mn = nullptr;
@@ -651,9 +673,15 @@ int run_bglight(uwip_ctx *ctx, const uwip_batch_u8 *in, int w, DzBufs &b, const 
             mn = (uint8_t *)uwip_ws(ctx, "dz.u8min", (size_t)3 * H * W * F);
             if (!mn) return UWIP_ERR_NOMEM;
         }
-        const int rc = uwip_winfilter15(ctx, img, in->step, in->frame_stride, F, H, W, b.u8planes, mn, mn ? b.si : nullptr, SI_COUNT);
+        unsigned long long *rs = nullptr;
+        if (mn) {
+            rs = (unsigned long long *)uwip_ws(ctx, "dz.redsum", sizeof(unsigned long long) * F);
+            if (!rs) return UWIP_ERR_NOMEM;
+        }
+        const int rc = uwip_winfilter15(ctx, img, in->step, in->frame_stride, F, H, W, b.u8planes, mn, mn ? b.si : nullptr, SI_COUNT, rs);
         if (rc) return rc;
         b.u8min = mn;
+        b.redsum = rs;
     } else {
         const size_t lds = (size_t)3 * (WF_TH + w - 1) * (WF_TW + w - 1) + (size_t)3 * (WF_TH + w - 1) * WF_TW;
         uwip_kscope ks(ctx, "k_winfilter<max>");
@@ -775,6 +803,7 @@ UWIP_API int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batc
     const uint8_t *img = (const uint8_t *)in->data;
     rc = run_bglight(ctx, in, w, b, d_B_inject, w == 15);
     if (rc) return rc;
+    bool fused_recover = false;
     if (b.u8min && uwip_gf_pu8_ok(img, in->step, in->frame_stride, b.u8min, 2, W, r)) {
         // the transmission is a per-frame function of the 8-bit window-minimum planes: the guided filter derives it on
         // the fly (uwip_gf_pu8) and the float64 P planes of k_transmission are never written
@@ -782,8 +811,17 @@ UWIP_API int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batc
         pu8.planes = b.u8min; pu8.nplanes = 3;
         pu8.sc = b.sc; pu8.sc_stride = SC_COUNT; pu8.b_off = SC_B0;
         pu8.tmin = tmin; pu8.w = 15; pu8.pad = 7;                     // refined_t drops w (BGDehaze.py:52, B-10)
-        rc = guided_filter_u8(ctx, img, in->step, in->frame_stride, b.si, SI_COUNT, nullptr, b.Q, b.AB, F, 2, H, W, r, eps, &pu8);
+        // ... and, unless the caller wants the refined t itself, recovers the scene in its second kernel
+        uwip_gf_recover rec;
+        rec.sc = b.sc; rec.sc_stride = SC_COUNT; rec.b_off = SC_B0;
+        fused_recover = !d_refined_t && b.redsum;
+        rc = guided_filter_u8(ctx, img, in->step, in->frame_stride, b.si, SI_COUNT, nullptr, b.Q, b.AB, F, 2, H, W, r, eps, &pu8,
+                              fused_recover ? &rec : nullptr);
         if (rc) return rc;
+        if (fused_recover) {
+            uwip_kscope ks(ctx, "k_recover");
+            k_recover_final2<<<F, 64, 0, ctx->stream>>>(rec.part, rec.nb, b.redsum, b.si, b.sc, (double)n);
+        }
     } else {
         rc = run_transmission(ctx, in, b, tmin, nullptr);
         if (rc) return rc;
@@ -792,7 +830,7 @@ UWIP_API int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batc
     }
     if (d_refined_t)
         UWIP_HIP(ctx, hipMemcpyAsync(d_refined_t, b.Q, sizeof(double) * 2 * n * F, hipMemcpyDeviceToDevice, ctx->stream));
-    {
+    if (!fused_recover) {
         uwip_kscope ks(ctx, "k_recover");
         k_recover<<<dim3(RED_BLOCKS, F), 256, 0, ctx->stream>>>(img, in->step, in->frame_stride, b.si, b.sc, b.Q, H, W, b.part);
         k_recover_final<<<F, 64, 0, ctx->stream>>>(b.part, RED_BLOCKS, b.sc, (double)n);

@@ -409,15 +409,20 @@ struct FinalRow {
     double v[4][4];   // [plane][column]
 };
 
-template <bool VEC>
+// REC (bgdehaze's scene recovery fused into the first filter, BGDehaze.py:50-52): instead of q = refined t the kernel
+// writes  J_ip = (normv(I_ip) - B_ip) / q + B_ip  and leaves each wave's min / max of J in `rec.part` -- the separate
+// k_recover pass (read 19 B + write 16 B per pixel) disappears.  Same operations as k_recover, in the same order.
+template <bool VEC, bool REC>
 __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S /*[Z][4][H][W]*/,
                                                     const uint8_t *__restrict__ guide, size_t step, size_t fs,
                                                     const int *__restrict__ gnorm, int gnorm_stride, int NP,
                                                     double *__restrict__ Q /*[Z][H][W]*/, int H, int W, int r, int TS,
-                                                    int rpc /*rows per chunk of S*/, int spw /*chains per wave*/, uint3 nb)
+                                                    int rpc /*rows per chunk of S*/, int spw /*chains per wave*/, uint3 nb,
+                                                    uwip_gf_recover rec)
 {
 #pragma clang fp contract(fast)
     __shared__ double2 s_d2[2 * 4 * 64];
+    __shared__ double s_nt[REC ? 256 : 1];
     unsigned bx, by, bz;
     if (!xcd_decode(nb.x, nb.y, nb.z, bx, by, bz)) return;
     StripGeom sg;
@@ -425,12 +430,23 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
     const int l = sg.l, z = bz, f = z / NP;
     const size_t n = (size_t)H * W;
     const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
+    double jmin = 1e300, jmax = -1e300, Bc = 0.0;
+    const int ipc = z - f * NP;          // the p plane = the guide channel this block recovers
+    double *jpart = REC ? rec.part + ((size_t)z * nb.x * nb.y + (size_t)by * nb.x + bx) * 2 : nullptr;
+    if (REC) {
+        Bc = rec.sc[(size_t)f * rec.sc_stride + rec.b_off + ipc];
+        for (int v = l; v < 256; v += 64) s_nt[v] = (double)(v - mn) / (double)(mx - mn);
+        wave_lds_fence();
+    }
     const uint8_t *gf = guide + (size_t)f * fs;
     const double *sp = S + (size_t)z * 4 * n;
     const int D = 2 * r + 1;
     const int s_end = min(min(D, H), (int)(by + 1) * spw);
     int s = by * spw, y = s;
-    if (s >= s_end) return;
+    if (s >= s_end) {
+        if (REC && l == 0) { jpart[0] = jmin; jpart[1] = jmax; }
+        return;
+    }
 
     // row buffers are zeroed once; load_row only overwrites in-image columns (yy must be a row of the image)
     auto clear_row = [&](FinalRow &R) {
@@ -530,6 +546,11 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
                 const double I0 = (double)(byte_of(gw, 3 * j) - mn) * rdd, I1 = (double)(byte_of(gw, 3 * j + 1) - mn) * rdd,
                              I2 = (double)(byte_of(gw, 3 * j + 2) - mn) * rdd;
                 qv[j] = ((hA.x - lA.x) * I0 + (hA.y - lA.y) * I1 + (hB.x - lB.x) * I2 + (hB.y - lB.y)) * rbase;
+                if (REC) {
+                    const double jv = (s_nt[byte_of(gw, 3 * j + ipc)] - Bc) / qv[j] + Bc;
+                    qv[j] = jv;
+                    jmin = fmin(jmin, jv); jmax = fmax(jmax, jv);
+                }
             }
         }
         double *o = Q + (size_t)z * n + (size_t)y * W + sg.x0;
@@ -556,6 +577,14 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
         if (!link(A, B)) break;
         if (!link(B, A)) break;
     }
+    if (REC) {
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            jmin = fmin(jmin, __shfl_xor(jmin, sft, 64));
+            jmax = fmax(jmax, __shfl_xor(jmax, sft, 64));
+        }
+        if (l == 0) { jpart[0] = jmin; jpart[1] = jmax; }
+    }
 }
 
 }  // namespace
@@ -570,7 +599,7 @@ bool uwip_gf_pu8_ok(const uint8_t *guide, size_t step, size_t fs, const uint8_t 
 
 int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs, const int *gnorm, int gstride,
                        const double *P, double *Q, double *AB, int F, int np, int H, int W, int r, double eps,
-                       const uwip_gf_pu8 *pu8)
+                       const uwip_gf_pu8 *pu8, uwip_gf_recover *rec)
 {
     UWIP_REQUIRE(ctx, np == 1 || np == 2, "np must be 1 or 2");
     UWIP_REQUIRE(ctx, r >= 1 && 2 * r <= 192, "radius out of range for the 256-column strip");
@@ -637,7 +666,9 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
     {
         // final: chains are independent, so split the 2r+1 chain starts over enough waves for ~4 rounds
         const unsigned Z = (unsigned)F * np;
-        const void *kfinal = vec ? (const void *)k_gf_ws_final<true> : (const void *)k_gf_ws_final<false>;
+        const void *kfinal = rec ? (const void *)k_gf_ws_final<true, true>
+                                 : vec ? (const void *)k_gf_ws_final<true, false> : (const void *)k_gf_ws_final<false, false>;
+        if (rec) UWIP_REQUIRE(ctx, vec && rec->sc, "fused recovery needs the aligned path");
         const int nchain = std::min(D, H);
         int groups = (int)std::ceil(4.0 * slots_of(kfinal) / ((double)strips * Z));
         const char *e = getenv("UWIP_GF_GROUPS");
@@ -647,8 +678,15 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
         const uint3 nb = make_uint3(strips, uwip_cdiv(nchain, spw), Z);
         const unsigned grid = 8u * ((nb.x * nb.y * nb.z + 7u) / 8u);
         uwip_kscope ks(ctx, "k_gf_ws_final");
-        if (vec) k_gf_ws_final<true><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw, nb);
-        else k_gf_ws_final<false><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw, nb);
+        const uwip_gf_recover none{};
+        if (rec) {
+            // one (min, max) pair per block of the launch; the caller reduces them
+            rec->nb = (int)(nb.x * nb.y);
+            rec->part = (double *)uwip_ws(ctx, "gf.jpart", sizeof(double) * 2 * (size_t)rec->nb * Z);
+            if (!rec->part) return UWIP_ERR_NOMEM;
+            k_gf_ws_final<true, true><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw, nb, *rec);
+        } else if (vec) k_gf_ws_final<true, false><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw, nb, none);
+        else k_gf_ws_final<false, false><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw, nb, none);
     }
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;

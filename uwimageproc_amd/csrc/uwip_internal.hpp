@@ -65,7 +65,7 @@ bool uwip_winfilter15_ok(const uint8_t *img, size_t step, size_t fs, int H, int 
 // stats (optional, both filters only): stats[f*stride + {0..3}] = min, max of all channels, min, max of channel 2,
 // by atomicMin / atomicMax onto the caller's 255 / 0 initial values
 int uwip_winfilter15(uwip_ctx *ctx, const uint8_t *img, size_t step, size_t fs, int F, int H, int W, uint8_t *out_max,
-                     uint8_t *out_min, int *stats = nullptr, int stats_stride = 0);
+                     uint8_t *out_min, int *stats = nullptr, int stats_stride = 0, unsigned long long *redsum = nullptr);
 // guided_filter_ws.hip: the wave-strip guided filter (guide u8 x3, P [F][np][H][W] -> Q, AB [F*np][4][H][W] scratch)
 // Optional 8-bit source of p (bgdehaze's transmission): plane ip of frame f is max(1 - normv(m) / B_ip, tmin) of the u8
 // plane m = planes[(f * nplanes + ip)][H][W], and 1 where the w x w window around the pixel leaves the image;
@@ -78,11 +78,20 @@ struct uwip_gf_pu8 {
     double tmin = 0.0;
     int w = 0, pad = 0;
 };
+// Optional fused scene recovery (bgdehaze D5) in the second kernel: Q receives J_ip = (normv(I_ip) - B_ip) / q + B_ip
+// instead of q, and part[(z * nb + block) * 2 + {0,1}] the per-block min / max of J (z = f * np + ip; `part` and `nb`
+// are filled in by uwip_gf_wave_strip).  Aligned path only.
+struct uwip_gf_recover {
+    const double *sc = nullptr;
+    int sc_stride = 0, b_off = 0;
+    double *part = nullptr;
+    int nb = 0;
+};
 // true when the 8-bit p source can be used for this geometry (aligned rows, W and r multiples of 4, np = 2)
 bool uwip_gf_pu8_ok(const uint8_t *guide, size_t step, size_t fs, const uint8_t *planes, int np, int W, int r);
 int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs, const int *gnorm, int gstride,
                        const double *P, double *Q, double *AB, int F, int np, int H, int W, int r, double eps,
-                       const uwip_gf_pu8 *pu8 = nullptr);
+                       const uwip_gf_pu8 *pu8 = nullptr, uwip_gf_recover *rec = nullptr);
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context, kernel)
 int uwip_lds_optin(uwip_ctx *ctx, const char *name, const void *func, size_t bytes);
 

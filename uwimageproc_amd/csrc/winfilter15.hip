@@ -123,10 +123,11 @@ struct VState {
 template <bool DO_MAX, bool DO_MIN>
 __global__ __launch_bounds__(64) void k_winfilter15(const uint8_t *__restrict__ img, size_t step, size_t fs, int H, int W,
                                                     uint8_t *__restrict__ out_max, uint8_t *__restrict__ out_min, int rpc,
-                                                    int *__restrict__ stats, int stats_stride)
+                                                    int *__restrict__ stats, int stats_stride,
+                                                    unsigned long long *__restrict__ redsum /*[F] or null: exact sum of channel 2*/)
 {
     constexpr bool BOTH = DO_MAX && DO_MIN;
-    uint32_t st_max = 0, st_imax = 0, st_rmax = 0, st_rimax = 0;
+    uint32_t st_max = 0, st_imax = 0, st_rmax = 0, st_rimax = 0, st_rsum = 0;
     const int l = threadIdx.x, f = blockIdx.z;
     const int col0 = (int)blockIdx.x * WF15_TS - 8 + 4 * l;      // image column of the lane's first sample
     const bool in = col0 >= 0 && col0 < W;                         // W % 4 == 0: all four or none
@@ -171,6 +172,9 @@ __global__ __launch_bounds__(64) void k_winfilter15(const uint8_t *__restrict__ 
 #pragma unroll
             for (int k = 0; k < 6; ++k) ui.v[k] = u.v[k] ^ xr;     // 255 - v inside the image, 0 outside
             if (BOTH) {
+                // every pixel belongs to exactly one (strip, row chunk): lanes 2..61 hold the strip's own 240 columns
+                if (y >= y0 && y < y1 && l >= 2 && l < 62)
+                    st_rsum += (u.v[4] & 0xffffu) + (u.v[4] >> 16) + (u.v[5] & 0xffffu) + (u.v[5] >> 16);
                 const uint32_t r = pkmax(u.v[4], u.v[5]), ri = pkmax(ui.v[4], ui.v[5]);
                 st_rmax = pkmax(st_rmax, r); st_rimax = pkmax(st_rimax, ri);
                 st_max = pkmax(st_max, pkmax(pkmax(pkmax(u.v[0], u.v[1]), pkmax(u.v[2], u.v[3])), r));
@@ -211,6 +215,12 @@ __global__ __launch_bounds__(64) void k_winfilter15(const uint8_t *__restrict__ 
             int *sp = stats + (size_t)f * stats_stride;
             atomicMin(&sp[0], 255 - b); atomicMax(&sp[1], a); atomicMin(&sp[2], 255 - d); atomicMax(&sp[3], c);
         }
+        if (redsum) {
+            uint32_t rs = st_rsum;
+#pragma unroll
+            for (int sft = 32; sft >= 1; sft >>= 1) rs += (uint32_t)__shfl_xor((int)rs, sft, 64);
+            if (l == 0) atomicAdd(&redsum[f], (unsigned long long)rs);
+        }
     }
 }
 
@@ -223,8 +233,9 @@ bool uwip_winfilter15_ok(const uint8_t *img, size_t step, size_t fs, int H, int 
 
 // out_max / out_min: planar [F][3][H][W] (either may be null)
 int uwip_winfilter15(uwip_ctx *ctx, const uint8_t *img, size_t step, size_t fs, int F, int H, int W, uint8_t *out_max,
-                     uint8_t *out_min, int *stats, int stats_stride)
+                     uint8_t *out_min, int *stats, int stats_stride, unsigned long long *redsum)
 {
+    UWIP_REQUIRE(ctx, !redsum || stats, "the red sum comes with the fused statistics");
     UWIP_REQUIRE(ctx, !stats || (out_max && out_min), "the fused statistics need both filters");
     UWIP_REQUIRE(ctx, uwip_winfilter15_ok(img, step, fs, H, W, 15), "k_winfilter15: unsupported geometry");
     UWIP_REQUIRE(ctx, out_max || out_min, "no output");
@@ -236,9 +247,10 @@ int uwip_winfilter15(uwip_ctx *ctx, const uint8_t *img, size_t step, size_t fs, 
     const int rpc = (H + chunks - 1) / chunks;
     const dim3 grid(strips, uwip_cdiv(H, rpc), (unsigned)F);
     uwip_kscope ks(ctx, "k_winfilter15");
-    if (out_max && out_min) k_winfilter15<true, true><<<grid, 64, 0, ctx->stream>>>(img, step, fs, H, W, out_max, out_min, rpc, stats, stats_stride);
-    else if (out_max) k_winfilter15<true, false><<<grid, 64, 0, ctx->stream>>>(img, step, fs, H, W, out_max, out_min, rpc, nullptr, 0);
-    else k_winfilter15<false, true><<<grid, 64, 0, ctx->stream>>>(img, step, fs, H, W, out_max, out_min, rpc, nullptr, 0);
+    if (redsum) UWIP_HIP(ctx, hipMemsetAsync(redsum, 0, sizeof(unsigned long long) * F, ctx->stream));
+    if (out_max && out_min) k_winfilter15<true, true><<<grid, 64, 0, ctx->stream>>>(img, step, fs, H, W, out_max, out_min, rpc, stats, stats_stride, redsum);
+    else if (out_max) k_winfilter15<true, false><<<grid, 64, 0, ctx->stream>>>(img, step, fs, H, W, out_max, out_min, rpc, nullptr, 0, nullptr);
+    else k_winfilter15<false, true><<<grid, 64, 0, ctx->stream>>>(img, step, fs, H, W, out_max, out_min, rpc, nullptr, 0, nullptr);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
