@@ -340,24 +340,36 @@ __global__ void k_recover_final(const double *__restrict__ part, int nb, double 
     s[SC_JMIN0] = a; s[SC_JMAX0] = b; s[SC_JMIN1] = c; s[SC_JMAX1] = d; s[SC_MEANR] = e / npix;
 }
 
-// Scene recovery fused into the guided filter (uwip_gf_recover): per-block (min, max) pairs of J for both planes, and the
-// mean of the normalised red channel from the exact integer sum of the red bytes:
-// mean((v - mn) / (mx - mn)) = (sum(v) - n mn) / (mx - mn) / n  (one rounding of an exact integer instead of n).
+// Scene recovery fused into the guided filter (uwip_gf_recover): per-block (min, max, sum) triples of J for both planes.
+// The frame scalars that k_recover / k_normJ and their finalisers produced come from them and from the exact integer
+// sum of the red bytes, each mean with ONE rounding of an exactly known total instead of n roundings:
+//   mean((v - mn) / (mx - mn))      = (sum(v) - n mn) / (mx - mn) / n
+//   mean((J - Jmin) / (Jmax - Jmin)) = (sum(J) - n Jmin) / (Jmax - Jmin) / n     (BGDehaze.py:54-64)
 __global__ void k_recover_final2(const double *__restrict__ jpart, int nb, const unsigned long long *__restrict__ redsum,
                                  const int *__restrict__ si, double *__restrict__ sc, double npix)
 {
     const int f = blockIdx.x;
     if (threadIdx.x != 0) return;
-    double a = 1e300, b = -1e300, c = 1e300, d = -1e300;
+    double a = 1e300, b = -1e300, c = 1e300, d = -1e300, s0 = 0.0, s1 = 0.0;
     for (int k = 0; k < nb; ++k) {
-        const double *p0 = jpart + ((size_t)(2 * f) * nb + k) * 2, *p1 = jpart + ((size_t)(2 * f + 1) * nb + k) * 2;
-        a = fmin(a, p0[0]); b = fmax(b, p0[1]); c = fmin(c, p1[0]); d = fmax(d, p1[1]);
+        const double *p0 = jpart + ((size_t)(2 * f) * nb + k) * 3, *p1 = jpart + ((size_t)(2 * f + 1) * nb + k) * 3;
+        a = fmin(a, p0[0]); b = fmax(b, p0[1]); s0 += p0[2];
+        c = fmin(c, p1[0]); d = fmax(d, p1[1]); s1 += p1[2];
     }
-    const int mn = si[(size_t)f * SI_COUNT + SI_MN], mx = si[(size_t)f * SI_COUNT + SI_MX];
+    const int *ii = si + (size_t)f * SI_COUNT;
+    const int mn = ii[SI_MN], mx = ii[SI_MX];
     const double sumr = (double)((long long)redsum[f] - (long long)npix * mn);
     double *s = sc + (size_t)f * SC_COUNT;
     s[SC_JMIN0] = a; s[SC_JMAX0] = b; s[SC_JMIN1] = c; s[SC_JMAX1] = d;
     s[SC_MEANR] = sumr / (double)(mx - mn) / npix;
+    s[SC_MEANJ0] = (s0 - npix * a) / (b - a) / npix;
+    s[SC_MEANJ1] = (s1 - npix * c) / (d - c) / npix;
+    // red-channel compensation coefficient and its min-max, as k_normJ_final
+    const double avgRr = 1.5 - s[SC_MEANJ0] - s[SC_MEANJ1];
+    const double coeff = avgRr / s[SC_MEANR];
+    s[SC_COEFF] = coeff;
+    const double lo = normv(ii[SI_RMN], mn, mx) * coeff, hi = normv(ii[SI_RMX], mn, mx) * coeff;
+    s[SC_RMIN] = fmin(lo, hi); s[SC_RMAX] = fmax(lo, hi);
 }
 
 // partial sums for the means of the min-max normalised J (BGDehaze.py:54,56,61).  J stays as it is in Q: every consumer
@@ -835,7 +847,7 @@ UWIP_API int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batc
         k_recover<<<dim3(RED_BLOCKS, F), 256, 0, ctx->stream>>>(img, in->step, in->frame_stride, b.si, b.sc, b.Q, H, W, b.part);
         k_recover_final<<<F, 64, 0, ctx->stream>>>(b.part, RED_BLOCKS, b.sc, (double)n);
     }
-    {
+    if (!fused_recover) {
         uwip_kscope ks(ctx, "k_normJ");
         k_normJ<<<dim3(RED_BLOCKS, F), 256, 0, ctx->stream>>>(b.Q, b.sc, H, W, b.part);
         k_normJ_final<<<F, 64, 0, ctx->stream>>>(b.part, RED_BLOCKS, b.si, b.sc, (double)n);

@@ -410,7 +410,7 @@ struct FinalRow {
 };
 
 // REC (bgdehaze's scene recovery fused into the first filter, BGDehaze.py:50-52): instead of q = refined t the kernel
-// writes  J_ip = (normv(I_ip) - B_ip) / q + B_ip  and leaves each wave's min / max of J in `rec.part` -- the separate
+// writes  J_ip = (normv(I_ip) - B_ip) / q + B_ip  and leaves each wave's min / max / sum of J in `rec.part` -- the separate
 // k_recover pass (read 19 B + write 16 B per pixel) disappears.  Same operations as k_recover, in the same order.
 template <bool VEC, bool REC>
 __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S /*[Z][4][H][W]*/,
@@ -430,9 +430,9 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
     const int l = sg.l, z = bz, f = z / NP;
     const size_t n = (size_t)H * W;
     const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
-    double jmin = 1e300, jmax = -1e300, Bc = 0.0;
+    double jmin = 1e300, jmax = -1e300, jsum = 0.0, Bc = 0.0;
     const int ipc = z - f * NP;          // the p plane = the guide channel this block recovers
-    double *jpart = REC ? rec.part + ((size_t)z * nb.x * nb.y + (size_t)by * nb.x + bx) * 2 : nullptr;
+    double *jpart = REC ? rec.part + ((size_t)z * nb.x * nb.y + (size_t)by * nb.x + bx) * 3 : nullptr;
     if (REC) {
         Bc = rec.sc[(size_t)f * rec.sc_stride + rec.b_off + ipc];
         for (int v = l; v < 256; v += 64) s_nt[v] = (double)(v - mn) / (double)(mx - mn);
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
     const int s_end = min(min(D, H), (int)(by + 1) * spw);
     int s = by * spw, y = s;
     if (s >= s_end) {
-        if (REC && l == 0) { jpart[0] = jmin; jpart[1] = jmax; }
+        if (REC && l == 0) { jpart[0] = jmin; jpart[1] = jmax; jpart[2] = 0.0; }
         return;
     }
 
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
                 if (REC) {
                     const double jv = (s_nt[byte_of(gw, 3 * j + ipc)] - Bc) / qv[j] + Bc;
                     qv[j] = jv;
-                    jmin = fmin(jmin, jv); jmax = fmax(jmax, jv);
+                    jmin = fmin(jmin, jv); jmax = fmax(jmax, jv); jsum += jv;
                 }
             }
         }
@@ -582,8 +582,9 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
         for (int sft = 32; sft >= 1; sft >>= 1) {
             jmin = fmin(jmin, __shfl_xor(jmin, sft, 64));
             jmax = fmax(jmax, __shfl_xor(jmax, sft, 64));
+            jsum += __shfl_xor(jsum, sft, 64);
         }
-        if (l == 0) { jpart[0] = jmin; jpart[1] = jmax; }
+        if (l == 0) { jpart[0] = jmin; jpart[1] = jmax; jpart[2] = jsum; }
     }
 }
 
@@ -682,7 +683,7 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
         if (rec) {
             // one (min, max) pair per block of the launch; the caller reduces them
             rec->nb = (int)(nb.x * nb.y);
-            rec->part = (double *)uwip_ws(ctx, "gf.jpart", sizeof(double) * 2 * (size_t)rec->nb * Z);
+            rec->part = (double *)uwip_ws(ctx, "gf.jpart", sizeof(double) * 3 * (size_t)rec->nb * Z);
             if (!rec->part) return UWIP_ERR_NOMEM;
             k_gf_ws_final<true, true><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw, nb, *rec);
         } else if (vec) k_gf_ws_final<true, false><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw, nb, none);

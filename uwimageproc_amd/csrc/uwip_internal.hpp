@@ -79,8 +79,8 @@ struct uwip_gf_pu8 {
     int w = 0, pad = 0;
 };
 // Optional fused scene recovery (bgdehaze D5) in the second kernel: Q receives J_ip = (normv(I_ip) - B_ip) / q + B_ip
-// instead of q, and part[(z * nb + block) * 2 + {0,1}] the per-block min / max of J (z = f * np + ip; `part` and `nb`
-// are filled in by uwip_gf_wave_strip).  Aligned path only.
+// instead of q, and part[(z * nb + block) * 3 + {0,1,2}] the per-block min / max / sum of J (z = f * np + ip; `part` and
+// `nb` are filled in by uwip_gf_wave_strip).  Aligned path only.
 struct uwip_gf_recover {
     const double *sc = nullptr;
     int sc_stride = 0, b_off = 0;
