@@ -197,13 +197,19 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
             const int batch = excess / 256;
             const int residual = excess - batch * 256;
             const int stepr = residual ? max(256 / residual, 1) : 1;
+            // v / stepr for v < 256, stepr <= 256 without a per-lane integer division (quarter-rate multiplies and a
+            // reciprocal sequence, eight times per clip limit): q = (v * m) >> 16 with m = floor(2^16 / stepr) + 1 is exact
+            // here, since v * (m * stepr - 2^16) <= 255 * 256 < 2^16.  stepr and m are wave-uniform.
+            const uint32_t magic = 65536u / (uint32_t)stepr + 1u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int v = lane * 4 + k;
                 h[k] += batch;
                 if (residual != 0) {
-                    if (rule == 0) { if (v % stepr == 0 && v / stepr < residual) h[k]++; }     // OpenCV 3.4.x
-                    else if (v < residual) h[k]++;                                             // OpenCV 3.2
+                    if (rule == 0) {                                                           // OpenCV 3.4.x
+                        const uint32_t q = __umul24((uint32_t)v, magic) >> 16;
+                        if (__umul24(q, (uint32_t)stepr) == (uint32_t)v && (int)q < residual) h[k]++;
+                    } else if (v < residual) h[k]++;                                           // OpenCV 3.2
                 }
             }
         }
