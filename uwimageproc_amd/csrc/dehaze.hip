@@ -41,6 +41,25 @@ __device__ __forceinline__ double normv(int v, int mn, int mx) { return (double)
 // An 8-bit sample takes 256 values, so every per-sample expression of the frame scalars is a 256-entry table: the
 // block's 256 threads evaluate it once (same operations, same roundings) and the pixel loop looks it up in LDS
 // instead of running float64 divisions per pixel.  Call with all 256 threads; ends with a barrier.
+// (row, column) of the pixels a thread visits in the loop  for (i = block * 256 + thread; i < n; i += grid * 256):
+// one 32-bit division up front, then a step of (stride / W, stride % W) -- not a 64-bit division per pixel.
+struct RowCol {
+    int x, y, dq, dr, W;
+    __device__ __forceinline__ explicit RowCol(int W_) : W(W_)
+    {
+        const uint32_t S = gridDim.x * 256u, i0 = blockIdx.x * 256u + threadIdx.x;
+        dq = (int)(S / (uint32_t)W);
+        dr = (int)(S - (uint32_t)dq * (uint32_t)W);
+        y = (int)(i0 / (uint32_t)W);
+        x = (int)(i0 - (uint32_t)y * (uint32_t)W);
+    }
+    __device__ __forceinline__ void step()
+    {
+        x += dr; y += dq;
+        if (x >= W) { x -= W; ++y; }
+    }
+};
+
 template <class F>
 __device__ __forceinline__ void fill_table256(double *tab, F f)
 {
@@ -282,8 +301,9 @@ __global__ __launch_bounds__(256) void k_transmission(const uint8_t *__restrict_
     __shared__ double s_Q0[256], s_Q1[256];
     s_Q0[threadIdx.x] = normv((int)threadIdx.x, mn, mx) / B0;
     fill_table256(s_Q1, [&](int v) { return normv(v, mn, mx) / B1; });
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+    RowCol rcw(W);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256, rcw.step()) {
+        const int y = rcw.y, x = rcw.x;
         // zero padding (BGDehaze.py:32): a window that leaves the image contains a 0
         const bool inside = (y - pad >= 0) && (y - pad + w <= H) && (x - pad >= 0) && (x - pad + w <= W);
         const double q0 = inside ? s_Q0[m0[i]] : 0.0;
@@ -311,8 +331,9 @@ __global__ __launch_bounds__(256) void k_recover(const uint8_t *__restrict__ img
     double mn0 = 1e300, mx0 = -1e300, mn1 = 1e300, mx1 = -1e300, sr = 0.0;
     __shared__ double s_T[256];
     fill_table256(s_T, [&](int v) { return normv(v, mn, mx); });
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+    RowCol rcw(W);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256, rcw.step()) {
+        const int y = rcw.y, x = rcw.x;
         const uint8_t *p = b + (size_t)y * step + (size_t)x * 3;
         const double j0 = (s_T[p[0]] - B0) / q0[i] + B0;
         const double j1 = (s_T[p[1]] - B1) / q1[i] + B1;
@@ -453,8 +474,9 @@ __global__ __launch_bounds__(256) void k_rc_out(const uint8_t *__restrict__ img,
     const double *q0 = Q + (size_t)f * 2 * n, *q1 = q0 + n;
     __shared__ double s_red[256];
     fill_red_table(s_red, s, mn, mx);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+    RowCol rcw(W);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256, rcw.step()) {
+        const int y = rcw.y, x = rcw.x;
         const uint8_t *p = img + (size_t)f * fs + (size_t)y * step + (size_t)x * 3;
         double v[3];
         restored_px(p, q0, q1, i, s, s_red, v);
@@ -495,8 +517,9 @@ __global__ __launch_bounds__(256) void k_exp_prep(const uint8_t *__restrict__ im
     __shared__ int s_u8[256];     // (normalised input * 255).astype(uint8) per 8-bit value
     s_u8[threadIdx.x] = trunc_u8(normv((int)threadIdx.x, mn, mx));
     fill_red_table(s_red, s, mn, mx);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+    RowCol rcw(W);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256, rcw.step()) {
+        const int y = rcw.y, x = rcw.x;
         const uint8_t *p = img + (size_t)f * fs + (size_t)y * step + (size_t)x * 3;
         double v[3];
         restored_px(p, q0, q1, i, s, s_red, v);
@@ -559,8 +582,9 @@ __global__ __launch_bounds__(256) void k_exp_out(const uint8_t *__restrict__ img
     double lo = 1e300, hi = -1e300, nanflag = 0.0;
     __shared__ double s_red[256];
     fill_red_table(s_red, s, mn, mx);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+    RowCol rcw(W);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256, rcw.step()) {
+        const int y = rcw.y, x = rcw.x;
         const uint8_t *p = img + (size_t)f * fs + (size_t)y * step + (size_t)x * 3;
         double v[3];
         restored_px(p, q0, q1, i, s, s_red, v);
