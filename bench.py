@@ -37,6 +37,10 @@ def parse():
     ap.add_argument("--cols", type=int, default=1920)
     ap.add_argument("--streams", type=int, default=4, help="independent sub-batches in flight per GPU (HIP streams + host threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-matcher-bench", dest="matcher_bench", action="store_false",
+                    help="skip the 2048 x 2048 matcher measurement (MFMA utilisation on BASELINE config 4's size)")
+    ap.add_argument("--no-host-buffers", dest="host_buffers", action="store_false",
+                    help="skip the upload/download-inclusive variant (timed on rank 0 after the main region)")
     ap.add_argument("--cpu-sample-rows", type=int, default=540)
     ap.add_argument("--cpu-sample-cols", type=int, default=960)
     return ap.parse_args()
@@ -80,21 +84,227 @@ def cpu_baseline(rows, cols, full_rows, full_cols):
     return sum(parts.values()), parts
 
 
-def pmc_traffic(kernel, rows, cols, frames_per_launch):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, corrected as
-    MI355X_MICROARCH.md prescribes; tools/prof_summary.py writes profiles/pmc_traffic.json).  The counters are
-    collected offline in their own rocprofv3 runs, so this is looked up, not measured in this process;
-    None when no matching profile is committed."""
+I8_MFMA_PEAK_TOPS = 5000.0     # dense i8 = 2x the ~2.5 PFLOP/s dense BF16 rate (MI355X_MICROARCH.md, Matrix cores)
+VALU_PEAK_GINSTR = 1024 * 2.4 / 4.0   # 1024 SIMDs, one wave64 VALU instruction per 4 clocks at the 2.4 GHz max clock
+
+# kernel name -> stage of the pipe
+STAGE_OF = [("k_ov_", "overlap"), ("k_hist_u8", "histretch"), ("k_compose_luts", "histretch"), ("k_stretch_lut", "histretch"),
+            ("k_apply_lut", "histretch"), ("k_bgr_to_v", "aclahe"), ("k_clahe_", "aclahe"), ("k_entropy", "aclahe"),
+            ("k_hsv_replace_v", "aclahe"), ("k_gauss3", "aclahe")]
+# SURVEY.md 8(d) algorithmic bytes per pixel (N = W*H):
+#   histretch "RGB": read 3N (hist) + read 3N + write 3N (apply)                                        =   9 N
+#   aclahe: sweep minimum 5 grids x 2N + final apply 3N = 13 N (8d), plus the colour conversions around it
+#           (BGR -> V: 3N + N; HSV merge: 3N + N read, 3N write)                                         =  24 N
+#   bgdehaze, from the implemented float64 pass list: k_winfilter15 3+6, k_bglight 3,
+#           filter 1 solve 3+2+64, final 64+3+16, k_exp_prep 3+16+3+1, k_exp_S 3+1+8, filter 3 solve 3+8+32,
+#           final 32+3+8, k_exp_out pass 0 3+16+8, pass 1 3+16+8+3                                       = 342 N
+STAGE_BYTES_PER_PIXEL = {"histretch": 9.0, "aclahe": 24.0, "bgdehaze": 342.0}
+
+
+def stage_of(kernel):
+    for pre, st in STAGE_OF:
+        if kernel.startswith(pre):
+            return st
+    return "bgdehaze"
+
+
+def pmc_entry(kernel, rows, cols):
+    """Committed counter digest of the same command (tools/pmc_digest.py over separate rocprofv3 --pmc passes; the
+    counters cannot be read inside this process).  None when no matching profile is committed."""
+    for name in ("r02_pmc.json", "pmc_traffic.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            e = d.get(f"{cols}x{rows}", {}).get(kernel)
+            if e is not None:
+                return e
+        except Exception:
+            pass
+    return None
+
+
+def matcher_report(ctx, dev, pairs=64):
+    """k_ov_match on a full 2048 x 2048 synthetic descriptor set per pair (BASELINE config 4 / SURVEY 8d):
+    ops = 2 * Kq * Kt * 512 per pair, timed with HIP events, against the dense i8 MFMA peak."""
+    import ctypes as C
+    rng = np.random.default_rng(7)
+    K = 2048
+    fh = C.c_void_p()
+    ctx.call("uwip_features_create", 2 * pairs, C.byref(fh))
+    kps = np.zeros((K, 8), dtype=np.int32)
+    kv = kps.view(np.float32)
+    kv[:, 0] = rng.uniform(8, 632, K); kv[:, 1] = rng.uniform(8, 352, K)
+    for slot in range(2 * pairs):
+        desc = rng.integers(0, 256, (K, 64), dtype=np.uint8)
+        desc[:, 60] &= 0x3f; desc[:, 61:] = 0                       # 486 payload bits, padded to 512
+        ctx.call("uwip_features_upload", fh, slot, 360, 640, C.c_void_p(kps.ctypes.data), C.c_void_p(desc.ctypes.data), K)
+    pq = (C.c_int32 * pairs)(*[2 * i for i in range(pairs)])
+    pt = (C.c_int32 * pairs)(*[2 * i + 1 for i in range(pairs)])
+    ratio = torch.empty((pairs,), dtype=torch.float32, device=dev)
+    ctx.prof_reset(); ctx.prof_enable(True)
+    reps = 3
+    for _ in range(reps):
+        ctx.call("uwip_overlap_match", fh, fh, pq, pt, pairs, 1920, 1080, 1, C.c_void_p(ratio.data_ptr()), None, None, None, None)
+    ctx.sync()
+    res = ctx.prof_results()
+    ctx.prof_enable(False)
+    ctx._l.uwip_features_destroy(fh)
+    ms, cnt = res["k_ov_match"]
+    avg = ms / cnt
+    ops = 2.0 * K * K * 512 * pairs
+    tops = ops / (avg * 1e-3) / 1e12
+    return {"kernel": "k_ov_match", "workload": f"{pairs} pairs x ({K} x {K}) 512-bit descriptors (config 4)", "ops_per_launch": ops,
+            "avg_launch_ms": avg, "achieved": tops, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": tops / I8_MFMA_PEAK_TOPS,
+            "bound": "mfma"}
+
+
+def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
+    import ctypes as C
+    from uwimageproc_amd import batch_of
+    N = H * W
+    ctx = pipe.ctx
+    ctx.prof_reset()
+    ctx.prof_enable(True)
+    nprof = max(1, min(args.steps, 3))
+    for _ in range(nprof):
+        pipe.run(part0)
+    torch.cuda.synchronize()
+    res = ctx.prof_results()
+    ctx.prof_enable(False)
+    kernels = {k: {"ms_per_step": ms / nprof, "launches_per_step": cnt / nprof, "stage": stage_of(k)} for k, (ms, cnt) in res.items()}
+    if "k_clahe_apply" not in res:
+        return None, kernels
+    tot = sum(v["ms_per_step"] for v in kernels.values())
+
+    def hbm_entry(kernel, bytes_per_frame, frames_per_launch, ms, cnt):
+        avg_ms = ms / cnt
+        per_launch = bytes_per_frame * frames_per_launch
+        ach = per_launch / (avg_ms * 1e-3) / 1e9
+        e = pmc_entry(kernel, H, W)
+        traffic = None if e is None else e["hbm_bytes_per_frame"] * frames_per_launch
+        return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else traffic / per_launch,
+                "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch}
+
+    # (1) the CLAHE kernel named by north_star: the final per-frame apply (read N + write N per frame), as launched
+    # by the step (one launch per 64-frame sub-batch: 265 MB at 1080p, about the size of the 256 MB Infinity Cache)
+    ms, cnt = res["k_clahe_apply"]
+    roof = hbm_entry("k_clahe_apply", 2.0 * N, Fs * nprof / cnt, ms, cnt)
+    roof["working_set"] = "one sub-batch launch of the step (input V written by the preceding pass; may hit in the Infinity Cache)"
+    # (1b) the same kernel on a working set the Infinity Cache cannot hold: ONE launch over >= 1 GB (V in + out of 256
+    # 1080p frames = 1.06 GB), input last touched a whole buffer ago
+    big_f = max(Fs, int(np.ceil(1.0e9 / (2.0 * N))))
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-        e = d.get(f"{cols}x{rows}", {}).get(kernel)
-        return None if e is None else e["hbm_bytes_per_frame"] * frames_per_launch
-    except Exception:
-        return None
+        vin = torch.randint(0, 256, (big_f, H, W), dtype=torch.uint8, device=dev)
+        vout = torch.empty_like(vin)
+        ib, ob = batch_of(vin), batch_of(vout)
+        ctx.call("uwip_clahe", C.byref(ib), C.byref(ob), C.c_double(3.0), 8, 8, 0)    # warm-up: tables, workspaces
+        ctx.sync()
+        ctx.prof_reset(); ctx.prof_enable(True)
+        for _ in range(3):
+            ctx.call("uwip_clahe", C.byref(ib), C.byref(ob), C.c_double(3.0), 8, 8, 0)
+        ctx.sync()
+        r2 = ctx.prof_results()
+        ctx.prof_enable(False)
+        ms2, cnt2 = r2["k_clahe_apply"]
+        big = hbm_entry("k_clahe_apply", 2.0 * N, big_f, ms2, cnt2)
+        big["working_set"] = f"one launch over {big_f} frames = {2.0 * N * big_f / 1e9:.2f} GB (> 256 MB Infinity Cache), CLAHE(3.0, 8x8)"
+        roof["large_working_set"] = big
+        del vin, vout
+    except Exception as e:                                    # never lose the bench line over the side measurement
+        roof["large_working_set"] = {"error": str(e)[:200]}
+    # (2) the kernel with the largest share of the step
+    dom_name = max(kernels.items(), key=lambda kv: kv[1]["ms_per_step"])[0]
+    dms, dcnt = res[dom_name]
+    if dom_name == "k_clahe_sweep":
+        # SURVEY 8(d): the sweep's algorithmic minimum is one read of the V plane per grid-size launch = N per frame
+        dom = hbm_entry(dom_name, 1.0 * N, Fs, dms, dcnt)        # every grid-size launch covers the whole sub-batch
+        dom["algorithmic_note"] = "8(d): one read of the V plane per grid size (N B per frame per launch); the kernel is VALU-issue bound, not HBM bound"
+    elif dom_name.startswith("k_gf_ws_solve"):
+        dom = hbm_entry(dom_name, (3 + 5 + 48) * N, Fs, dms, dcnt)
+        dom["algorithmic_note"] = "per frame, averaged over the two launches of a step (filter 1: guide 3N + two 8-bit p planes 2N read, 64N written; filter 3: 3N + 8N read, 32N written)"
+    else:
+        dom = {"kernel": dom_name, "avg_launch_ms": dms / dcnt}
+    dom["ms_per_step"] = kernels[dom_name]["ms_per_step"]
+    dom["share_of_step"] = kernels[dom_name]["ms_per_step"] / tot
+    e = pmc_entry(dom_name, H, W)
+    if e is not None and e.get("valu_insts_per_frame"):
+        ginstr = e["valu_insts_per_frame"] * (Fs * nprof / dcnt) / ((dms / dcnt) * 1e-3) / 1e9
+        dom["valu"] = {"wave_instr_per_launch": e["valu_insts_per_frame"] * (Fs * nprof / dcnt), "achieved_Ginstr_per_s": ginstr,
+                       "peak_Ginstr_per_s": VALU_PEAK_GINSTR, "frac": ginstr / VALU_PEAK_GINSTR,
+                       "source": "SQ_INSTS_VALU of the committed rocprofv3 --pmc pass (profiles/), time from this run"}
+    roof["dominant"] = dom
+    # (3) per stage: kernel time against the stage's 8(d) algorithmic bytes
+    stages = {}
+    for k, v in kernels.items():
+        st = stages.setdefault(v["stage"], {"ms_per_step": 0.0})
+        st["ms_per_step"] += v["ms_per_step"]
+    for name, st in stages.items():
+        st["share_of_step"] = st["ms_per_step"] / tot
+        if name in STAGE_BYTES_PER_PIXEL:
+            by = STAGE_BYTES_PER_PIXEL[name] * N * Fs
+            st["algorithmic_bytes_per_step"] = by
+            st["achieved_GBps"] = by / (st["ms_per_step"] * 1e-3) / 1e9
+            st["frac_of_hbm_peak"] = st["achieved_GBps"] / HBM_PEAK_GBS
+    roof["stages"] = stages
+    roof["step_kernel_ms"] = tot
+    top = sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])[:3]
+    roof["largest_kernels"] = [{"kernel": k, "ms_per_step": v["ms_per_step"], "share": v["ms_per_step"] / tot} for k, v in top]
+    # (4) the matcher against the dense i8 MFMA peak: at the step's own keypoint counts and on a full 2048 x 2048 set
+    if "k_ov_match" in res:
+        info = pipe.info.cpu().numpy()
+        mms, mcnt = res["k_ov_match"]
+        ops = float(sum(2.0 * int(r[0]) * int(r[1]) * 512 for r in info)) * 1.0
+        tops = ops / ((mms / mcnt) * 1e-3) / 1e12
+        roof["matcher"] = {"in_step": {"kernel": "k_ov_match", "pairs": int(len(info)), "mean_keypoints": float(np.mean(info[:, 0])),
+                                       "ops_per_launch": ops, "avg_launch_ms": mms / mcnt, "achieved": tops, "peak": I8_MFMA_PEAK_TOPS,
+                                       "unit": "TOP/s", "frac": tops / I8_MFMA_PEAK_TOPS, "bound": "mfma"}}
+        if args.matcher_bench:
+            try:
+                roof["matcher"]["config4_2048x2048"] = matcher_report(ctx, dev)
+            except Exception as ex:
+                roof["matcher"]["config4_2048x2048"] = {"error": str(ex)[:200]}
+    return roof, kernels
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE this
+    process touches the GPU, relay rank 0's JSON line, and exit with the worst return code.  With fewer
+    visible devices than ranks (a 1-GPU box) the ranks share devices and rendezvous over gloo -- a plumbing
+    rehearsal, flagged "ranks_share_gpu" in the line."""
+    import subprocess
+    n = args.gpus
+    ndev = torch.cuda.device_count()          # does not initialise the GPU on this image
+    env = dict(os.environ)
+    env.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
+                "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    if ndev < n:
+        env["UWIP_BENCH_BACKEND"] = "gloo"
+    procs = []
+    for r in range(n):
+        e = dict(env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r)})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for pr in procs[1:]:
+        rc = max(rc, abs(pr.wait()))
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(rc)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,7 +338,7 @@ def main():
     # S independent pipes, each on its own HIP stream and driven by its own host thread: frames are independent
     # units, so the HBM-bound dehaze passes of one half-batch overlap the LDS-bound sweep and the host-side
     # ACLAHE parameter choice of the other
-    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+    streams = [torch.cuda.Stream(dev) for _ in range(S)]
     pipes = []
     for i in range(S):
         with torch.cuda.stream(streams[i]):
@@ -136,20 +346,22 @@ def main():
     pipe = pipes[0]
     parts = [src[i * Fs:(i + 1) * Fs] for i in range(S)]
 
-    def run_step():
+    import threading
+
+    def on_all_pipes(fn):
+        """fn(i) for every sub-batch, each on its own host thread (a uwip context is single-threaded; one per thread)"""
         if S == 1:
-            pipes[0].run(parts[0])
+            fn(0)
             return
-        import threading
-        def work(i):
-            with torch.cuda.stream(streams[i]):
-                pipes[i].run(parts[i])
-        th = [threading.Thread(target=work, args=(i,)) for i in range(1, S)]
+        th = [threading.Thread(target=fn, args=(i,)) for i in range(1, S)]
         for t in th:
             t.start()
-        work(0)
+        fn(0)
         for t in th:
             t.join()
+
+    def run_step():
+        on_all_pipes(lambda i: pipes[i].run(parts[i]))
 
     def barrier():
         if world > 1:
@@ -171,36 +383,43 @@ def main():
     from uwimageproc_amd import sharding
     dt = sharding.max_over_ranks(dt)          # the slowest rank defines the step time
 
+    # Host-buffer variant (reported next to `value`, never as `value`): the reference's own timed region brackets
+    # upload ... download (histretch.cpp:165,174-175,212-213,257-261).  Every step copies its frames from page-locked
+    # host memory to HBM and the processed frames back, with the library's own staging buffers and
+    # hipMemcpyAsync on each sub-batch's stream (uwip_host_alloc / uwip_memcpy_*_async); the copies of one
+    # sub-batch overlap the kernels of the other three.
+    host = None
+    if args.host_buffers and world == 1:
+        bufs = [pipes[i].host_buffers() for i in range(S)]
+        for i in range(S):
+            bufs[i][0][...] = parts[i].cpu().numpy()
+        torch.cuda.synchronize()
+
+        def step_host():
+            on_all_pipes(lambda i: pipes[i].run_host(*bufs[i]))
+
+        step_host()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_host()
+        torch.cuda.synchronize()
+        dt_h = time.perf_counter() - t1
+        same = all(np.array_equal(bufs[i][1], pipes[i].work.cpu().numpy()) for i in range(S))
+        host = {"value": F * args.steps / dt_h, "unit": "frames/s", "ms_per_step": dt_h / args.steps * 1e3,
+                "gbytes_per_s_each_way": F * H * W * 3 * args.steps / dt_h / 1e9, "downloaded_equals_device": bool(same),
+                "note": "same steps on this rank with page-locked host -> HBM and HBM -> page-locked host copies of every "
+                        "frame inside the timed region (library staging buffers, hipMemcpyAsync on the sub-batch's stream)"}
+        for i in range(S):
+            for a in bufs[i]:
+                pipes[i].ctx.host_free(a)
+        del bufs
+
     # per-kernel timing pass (HIP events on the launch stream, inside libuwip)
     roof = None
     kernels = {}
     if rank == 0:
-        pipe.ctx.prof_reset()
-        pipe.ctx.prof_enable(True)
-        nprof = max(1, min(args.steps, 3))
-        for _ in range(nprof):
-            pipe.run(parts[0])
-        torch.cuda.synchronize()
-        res = pipe.ctx.prof_results()
-        pipe.ctx.prof_enable(False)
-        kernels = {k: {"ms_per_step": ms / nprof, "launches_per_step": cnt / nprof} for k, (ms, cnt) in res.items()}
-        N = H * W
-        # the CLAHE kernel named by north_star: the final per-frame apply (read N + write N per frame)
-        if "k_clahe_apply" in res:
-            ms, cnt = res["k_clahe_apply"]
-            per_launch_bytes = 2.0 * N * Fs * nprof / cnt
-            avg_ms = ms / cnt
-            achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "k_clahe_apply", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic("k_clahe_apply", H, W, Fs * nprof / cnt), "avg_launch_ms": avg_ms,
-                    "algorithmic_bytes_per_launch": per_launch_bytes}
-        # for orientation: the kernels that actually dominate the step (the sweep is VALU-issue bound, the guided-filter
-        # kernels HBM / VALU bound: DESIGN.md section 5, profiles/r01_sq_counters.txt)
-        if roof is not None and kernels:
-            tot = sum(v["ms_per_step"] for v in kernels.values())
-            top = sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])[:3]
-            roof["step_kernel_ms"] = tot
-            roof["largest_kernels"] = [{"kernel": k, "ms_per_step": v["ms_per_step"], "share": v["ms_per_step"] / tot} for k, v in top]
+        roof, kernels = roofline_report(args, pipe, parts[0], dev, F, Fs, H, W)
 
     if rank == 0:
         cpu = None
@@ -218,6 +437,7 @@ def main():
             "value": total_frames / dt,
             "unit": "frames/s",
             "n_gpus": world,
+            "ranks_share_gpu": bool(world > max(ndev, 1)),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -231,6 +451,7 @@ def main():
                        "parallelism": f"frame-batch x{world}"},
             "roofline": roof,
             "cpu_baseline": cpu,
+            "host_buffers": host,
             "kernels": kernels,
         }
         print(json.dumps(line))

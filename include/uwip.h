@@ -63,6 +63,21 @@ typedef struct uwip_batch_u8 {
  * let the context create its own. */
 int uwip_device_count(int *count);
 int uwip_ctx_create(int device, void *stream, uwip_ctx **out);
+/* Same with flags.  UWIP_CTX_STREAM_GIVEN: `stream` is used as it is even when
+ * it is NULL -- the handle of the device's default ("null") stream is 0, which
+ * uwip_ctx_create cannot tell from "no stream given"; a host framework whose
+ * current stream is the default one (torch's is, until a side stream is made
+ * current) passes this flag so that its own work and the library's stay in one
+ * stream order.
+ *
+ * Threading: a uwip_ctx (and every uwip_features made from it) is
+ * single-threaded -- one host thread at a time may be inside calls on it; the
+ * library keeps no state outside contexts, so different contexts may be used
+ * from different threads concurrently (one context per host thread / stream,
+ * as bench.py does).  Every entry point makes the context's device current for
+ * the calling thread (hipSetDevice) before it allocates, copies or launches. */
+#define UWIP_CTX_STREAM_GIVEN 1u
+int uwip_ctx_create_ex(int device, void *stream, unsigned flags, uwip_ctx **out);
 int uwip_ctx_destroy(uwip_ctx *ctx);
 const char *uwip_last_error(const uwip_ctx *ctx);
 const char *uwip_version(void);
@@ -73,6 +88,15 @@ int uwip_malloc(uwip_ctx *ctx, size_t bytes, void **d_ptr);
 int uwip_free(uwip_ctx *ctx, void *d_ptr);
 int uwip_memcpy_h2d(uwip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int uwip_memcpy_d2h(uwip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+/* The same transfers enqueued on the context's stream without waiting
+ * (GpuMat::upload / download with a cuda::Stream): the host buffer must be
+ * page-locked -- take it from uwip_host_alloc (cuda::HostMem, PAGE_LOCKED) --
+ * and stay untouched until uwip_sync().  This is the host-buffer front end of
+ * the timed region of histretch.cpp:165-216 (upload ... download). */
+int uwip_host_alloc(uwip_ctx *ctx, size_t bytes, void **h_ptr);
+int uwip_host_free(uwip_ctx *ctx, void *h_ptr);
+int uwip_memcpy_h2d_async(uwip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int uwip_memcpy_d2h_async(uwip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 
 /* Per-kernel hipEvent timing on the context's stream (replaces the
  * getTickCount stopwatch, histretch.cpp:165,257-261).  Enabling it brackets
@@ -247,6 +271,11 @@ int uwip_overlap_detect(uwip_ctx *ctx, const uwip_batch_u8 *frames, uwip_feature
  * of rows*cols floats, any may be NULL). */
 int uwip_features_download(uwip_ctx *ctx, const uwip_features *feats, int slot, void *h_kps,
                            uint8_t *h_desc, int32_t *h_count);
+/* the opposite direction: fill one slot from host keypoints (uwip_keypoint[count]) and packed
+ * descriptors ([count][64]); the reference's `struct keyframe` members are public and caller-fillable
+ * (videostrip.hpp:62-68).  rows/cols: the working size the keypoints refer to. */
+int uwip_features_upload(uwip_ctx *ctx, uwip_features *feats, int slot, int rows, int cols,
+                         const void *h_kps, const uint8_t *h_desc, int32_t count);
 int uwip_overlap_debug_level(uwip_ctx *ctx, int frame, int level, int rows, int cols, float *h_Lt,
                              float *h_Lx, float *h_Ly, float *h_Ldet, float *h_kcontrast);
 /* h_pair_q / h_pair_t: host arrays of slot indices (query = object frame in fq, train = key

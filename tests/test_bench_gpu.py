@@ -1,0 +1,35 @@
+"""GPU: `python bench.py --gpus 2` must work by itself (no launcher): it starts two fresh rank processes before
+touching the GPU; on a 1-GPU box they share the device and rendezvous over gloo (plumbing rehearsal)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _run(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--frames", "8", "--streams", "2",
+           "--rows", "270", "--cols", "480", "--no-cpu-baseline", "--no-matcher-bench"] + extra
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line"
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks():
+    one = _run(["--gpus", "1"])
+    two = _run(["--gpus", "2", "--no-host-buffers"])
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["frames_per_gpu_per_step"] == 8
+    # whole-job frames per step doubles with the ranks (weak scaling): value * ms_per_step = frames per step
+    f1 = one["value"] * one["ms_per_step"] / 1e3
+    f2 = two["value"] * two["ms_per_step"] / 1e3
+    assert abs(f1 - 8) < 1e-6 and abs(f2 - 16) < 1e-6
+    assert one["host_buffers"] is not None and one["host_buffers"]["downloaded_equals_device"]
+    assert one["roofline"] is not None and "dominant" in one["roofline"]

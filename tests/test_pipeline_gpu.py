@@ -151,3 +151,72 @@ def test_degenerate_frames_run_clean(kind):
     assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][2] == outs[1][2]
     assert np.array_equal(outs[0][1], outs[1][1], equal_nan=True)
     assert np.array_equal(outs[0][0][0], outs[0][0][1])          # identical frames -> identical outputs
+
+
+def test_context_shares_torchs_default_stream():
+    """The handle of torch's default stream is 0; a context given that handle must run ON that stream (round 1
+    silently made a private stream instead, so a producer enqueued by torch just before a library call was not
+    ordered before it -- the stream aliasing behind the host-buffer bench variant's unordered copies)."""
+    import ctypes as C
+    import uwimageproc_amd as uw
+    from uwimageproc_amd import batch_of
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    assert torch.cuda.current_stream(dev).cuda_stream == 0
+    c = uw.Context(0, stream=0)
+    img = torch.zeros((4, 1080, 1920, 3), dtype=torch.uint8, device=dev)
+    fill = torch.full_like(img, 7)
+    hist = torch.zeros((4, 3, 256), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    torch.cuda._sleep(400_000_000)          # ~0.2 s of GPU time on torch's current (default) stream
+    img.copy_(fill)                         # the producer, queued behind the sleep
+    b = batch_of(img)
+    c.call("uwip_getHistogram", C.byref(b), C.c_void_p(hist.data_ptr()))   # must be ordered after it
+    torch.cuda.synchronize()
+    h = hist.cpu().numpy()
+    assert (h[:, :, 7] == 1080 * 1920).all() and h.sum() == 4 * 3 * 1080 * 1920
+    c.close()
+    # a context created without a stream owns a private one and is NOT ordered with torch (by design)
+    c2 = uw.Context(0)
+    c2.close()
+
+
+def test_host_buffer_front_end_equals_device_path():
+    """upload -> pipe -> download through the library's page-locked buffers and stream-ordered copies gives the
+    bytes the HBM-resident path gives; two pipes on two streams from two host threads (the bench's arrangement)."""
+    import threading
+    F, H, W = 2, 270, 480
+    dev = torch.device("cuda", 0)
+    frames = [synth.uw_stream(10 * i, F, H, W) for i in range(2)]
+    ref = []
+    for i in range(2):
+        p = FramePipe(0, F, H, W, video_size=(640, 480))
+        out, ratio = p.run(torch.from_numpy(frames[i]).cuda())
+        torch.cuda.synchronize()
+        ref.append((out.cpu().numpy().copy(), ratio.cpu().numpy().copy()))
+        p.close()
+    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    pipes, bufs = [], []
+    for i in range(2):
+        with torch.cuda.stream(streams[i]):
+            pipes.append(FramePipe(0, F, H, W, video_size=(640, 480)))
+        bufs.append(pipes[i].host_buffers())
+        bufs[i][0][...] = frames[i]
+        bufs[i][1][...] = 0
+
+    def work(i):
+        for _ in range(2):
+            pipes[i].have_prev = False
+            pipes[i].run_host(*bufs[i])
+        pipes[i].ctx.sync()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        assert np.array_equal(bufs[i][1], ref[i][0])
+        assert np.allclose(pipes[i].ratio.cpu().numpy(), ref[i][1], atol=0)
+        for a in bufs[i]:
+            pipes[i].ctx.host_free(a)
+        pipes[i].close()

@@ -49,6 +49,7 @@ _B = C.POINTER(BatchU8)
 SIGNATURES = {
     "uwip_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "uwip_ctx_create": (C.c_int, [C.c_int, _P, C.POINTER(_P)]),
+    "uwip_ctx_create_ex": (C.c_int, [C.c_int, _P, C.c_uint, C.POINTER(_P)]),
     "uwip_ctx_destroy": (C.c_int, [_P]),
     "uwip_last_error": (C.c_char_p, [_P]),
     "uwip_version": (C.c_char_p, []),
@@ -57,6 +58,10 @@ SIGNATURES = {
     "uwip_free": (C.c_int, [_P, _P]),
     "uwip_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "uwip_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "uwip_host_alloc": (C.c_int, [_P, C.c_size_t, C.POINTER(_P)]),
+    "uwip_host_free": (C.c_int, [_P, _P]),
+    "uwip_memcpy_h2d_async": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "uwip_memcpy_d2h_async": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "uwip_prof_enable": (C.c_int, [_P, C.c_int]),
     "uwip_prof_reset": (C.c_int, [_P]),
     "uwip_prof_count": (C.c_int, [_P, C.POINTER(C.c_int)]),
@@ -88,6 +93,7 @@ SIGNATURES = {
     "uwip_overlap_working_size": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "uwip_overlap_detect": (C.c_int, [_P, _B, _P, C.c_int]),
     "uwip_features_download": (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(C.c_int32)]),
+    "uwip_features_upload": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int32]),
     "uwip_overlap_debug_level": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "uwip_overlap_match": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
                                      C.c_uint32, _P, _P, _P, _P, _P]),
@@ -121,12 +127,19 @@ def device_count() -> int:
 
 
 class Context:
-    """Owns a ``uwip_ctx``.  ``stream`` may be a raw hipStream_t handle (int)."""
+    """Owns a ``uwip_ctx``.  ``stream`` = None: the context creates its own stream; an int: that raw
+    hipStream_t handle is used as it is -- including 0, the device's default stream (which is what
+    ``torch.cuda.current_stream().cuda_stream`` is until a side stream is made current)."""
+
+    UWIP_CTX_STREAM_GIVEN = 1
 
     def __init__(self, device: int = 0, stream: Optional[int] = None):
         self._l = lib()
         h = _P()
-        rc = self._l.uwip_ctx_create(int(device), _P(stream) if stream else None, C.byref(h))
+        if stream is None:
+            rc = self._l.uwip_ctx_create(int(device), None, C.byref(h))
+        else:
+            rc = self._l.uwip_ctx_create_ex(int(device), _P(int(stream)), self.UWIP_CTX_STREAM_GIVEN, C.byref(h))
         if rc != UWIP_OK:
             raise UwipError(rc, "uwip_ctx_create failed (no HIP device? there is no CPU fallback)")
         self._h = h
@@ -152,6 +165,35 @@ class Context:
 
     def sync(self):
         self.call("uwip_sync")
+
+    # ---- page-locked host buffers + stream-ordered transfers (GpuMat::upload / download with a stream) ----
+    def host_alloc(self, shape, dtype="uint8"):
+        """A numpy array over page-locked host memory owned by the library (freed by ``host_free``)."""
+        import numpy as np
+
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        p = _P()
+        self.call("uwip_host_alloc", n, C.byref(p))
+        buf = (C.c_uint8 * n).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dt).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p
+        return a
+
+    def host_free(self, a):
+        p = self._pinned.pop(a.ctypes.data)
+        self.call("uwip_host_free", p)
+
+    def h2d_async(self, d_tensor, h_array):
+        assert d_tensor.is_contiguous() and h_array.flags.c_contiguous
+        assert d_tensor.numel() * d_tensor.element_size() == h_array.nbytes
+        self.call("uwip_memcpy_h2d_async", _P(d_tensor.data_ptr()), _P(h_array.ctypes.data), h_array.nbytes)
+
+    def d2h_async(self, h_array, d_tensor):
+        assert d_tensor.is_contiguous() and h_array.flags.c_contiguous
+        assert d_tensor.numel() * d_tensor.element_size() == h_array.nbytes
+        self.call("uwip_memcpy_d2h_async", _P(h_array.ctypes.data), _P(d_tensor.data_ptr()), h_array.nbytes)
 
     # ---- profiling ----
     def prof_enable(self, on: bool = True):

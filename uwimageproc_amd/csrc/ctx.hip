@@ -1,5 +1,6 @@
 // Context, device memory and per-kernel event profiling for libuwip.so.
 #include "uwip_internal.hpp"
+#include <cstdlib>
 #include <cstring>
 
 UWIP_API const char *uwip_version(void) { return "uwip-mi355x 0.1 (gfx950)"; }
@@ -14,10 +15,25 @@ UWIP_API int uwip_device_count(int *count)
     return UWIP_OK;
 }
 
-UWIP_API int uwip_ctx_create(int device, void *stream, uwip_ctx **out)
+// UWIP_TRACE_ALLOC=1: every device / pinned allocation of the library is reported on stderr with its address range,
+// so that a faulting address in a GPU memory-access fault report can be attributed to a buffer (or to none of ours).
+static bool trace_alloc()
+{
+    static const bool on = [] { const char *e = std::getenv("UWIP_TRACE_ALLOC"); return e && *e && *e != '0'; }();
+    return on;
+}
+void uwip_trace_range(const uwip_ctx *ctx, const char *kind, const char *name, const void *p, size_t bytes)
+{
+    if (!trace_alloc()) return;
+    std::fprintf(stderr, "[uwip alloc] ctx=%p stream=%p %s %s [%p, %p) %zu B\n", (const void *)ctx,
+                 ctx ? (const void *)ctx->stream : nullptr, kind, name, p, (const void *)((const char *)p + bytes), bytes);
+}
+
+UWIP_API int uwip_ctx_create_ex(int device, void *stream, unsigned flags, uwip_ctx **out)
 {
     if (!out) return UWIP_ERR_INVALID;
     *out = nullptr;
+    if (flags & ~(unsigned)UWIP_CTX_STREAM_GIVEN) return UWIP_ERR_INVALID;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return UWIP_ERR_HIP;  // no CPU fallback
     if (device < 0 || device >= n) return UWIP_ERR_INVALID;
@@ -25,7 +41,8 @@ UWIP_API int uwip_ctx_create(int device, void *stream, uwip_ctx **out)
     uwip_ctx *ctx = new (std::nothrow) uwip_ctx();
     if (!ctx) return UWIP_ERR_NOMEM;
     ctx->device = device;
-    if (stream) {
+    if (stream || (flags & UWIP_CTX_STREAM_GIVEN)) {
+        // a NULL handle with UWIP_CTX_STREAM_GIVEN is the device's default (null) stream itself
         ctx->stream = (hipStream_t)stream;
         ctx->own_stream = false;
     } else {
@@ -38,6 +55,8 @@ UWIP_API int uwip_ctx_create(int device, void *stream, uwip_ctx **out)
     *out = ctx;
     return UWIP_OK;
 }
+
+UWIP_API int uwip_ctx_create(int device, void *stream, uwip_ctx **out) { return uwip_ctx_create_ex(device, stream, 0u, out); }
 
 UWIP_API int uwip_ctx_destroy(uwip_ctx *ctx)
 {
@@ -58,7 +77,7 @@ UWIP_API const char *uwip_last_error(const uwip_ctx *ctx) { return ctx ? ctx->er
 
 UWIP_API int uwip_sync(uwip_ctx *ctx)
 {
-    if (!ctx) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return UWIP_OK;
 }
@@ -66,16 +85,17 @@ UWIP_API int uwip_sync(uwip_ctx *ctx)
 UWIP_API int uwip_malloc(uwip_ctx *ctx, size_t bytes, void **d_ptr)
 {
     if (!ctx || !d_ptr) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     *d_ptr = nullptr;
     if (bytes == 0) return UWIP_OK;
-    UWIP_HIP(ctx, hipSetDevice(ctx->device));
     UWIP_HIP(ctx, hipMalloc(d_ptr, bytes));
+    uwip_trace_range(ctx, "device", "uwip_malloc", *d_ptr, bytes);
     return UWIP_OK;
 }
 
 UWIP_API int uwip_free(uwip_ctx *ctx, void *d_ptr)
 {
-    if (!ctx) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     if (!d_ptr) return UWIP_OK;
     UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     UWIP_HIP(ctx, hipFree(d_ptr));
@@ -84,7 +104,7 @@ UWIP_API int uwip_free(uwip_ctx *ctx, void *d_ptr)
 
 UWIP_API int uwip_memcpy_h2d(uwip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
 {
-    if (!ctx) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     if (bytes == 0) return UWIP_OK;
     UWIP_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -93,10 +113,48 @@ UWIP_API int uwip_memcpy_h2d(uwip_ctx *ctx, void *d_dst, const void *h_src, size
 
 UWIP_API int uwip_memcpy_d2h(uwip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
 {
-    if (!ctx) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     if (bytes == 0) return UWIP_OK;
     UWIP_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_host_alloc(uwip_ctx *ctx, size_t bytes, void **h_ptr)
+{
+    if (!ctx || !h_ptr) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
+    *h_ptr = nullptr;
+    if (bytes == 0) return UWIP_OK;
+    UWIP_HIP(ctx, hipHostMalloc(h_ptr, bytes, hipHostMallocDefault));
+    uwip_trace_range(ctx, "pinned", "uwip_host_alloc", *h_ptr, bytes);
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_host_free(uwip_ctx *ctx, void *h_ptr)
+{
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
+    if (!h_ptr) return UWIP_OK;
+    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // copies still queued on this context's stream
+    UWIP_HIP(ctx, hipHostFree(h_ptr));
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_memcpy_h2d_async(uwip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
+    if (bytes == 0) return UWIP_OK;
+    UWIP_REQUIRE(ctx, d_dst && h_src, "null buffer");
+    UWIP_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_memcpy_d2h_async(uwip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
+    if (bytes == 0) return UWIP_OK;
+    UWIP_REQUIRE(ctx, h_dst && d_src, "null buffer");
+    UWIP_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     return UWIP_OK;
 }
 
@@ -118,6 +176,7 @@ void *uwip_ws(uwip_ctx *ctx, const char *name, size_t bytes)
         return nullptr;
     }
     b.bytes = want;
+    uwip_trace_range(ctx, "device", name, b.ptr, want);
     return b.ptr;
 }
 
@@ -138,6 +197,7 @@ void *uwip_host_ws(uwip_ctx *ctx, const char *name, size_t bytes)
         return nullptr;
     }
     b.bytes = want;
+    uwip_trace_range(ctx, "pinned", name, b.ptr, want);
     return b.ptr;
 }
 
@@ -157,11 +217,15 @@ const void *uwip_table_put(uwip_ctx *ctx, const std::string &key, const void *ho
         return nullptr;
     }
     b.bytes = bytes;
-    if (bytes && hipMemcpy(b.ptr, host, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+    // on the context's own stream (not the null stream, which another thread may be using), and drained before
+    // `host` -- usually a local std::vector of the caller -- goes away
+    if (bytes && (hipMemcpyAsync(b.ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                  hipStreamSynchronize(ctx->stream) != hipSuccess)) {
         (void)hipFree(b.ptr);
         ctx->fail(UWIP_ERR_HIP, "table upload");
         return nullptr;
     }
+    uwip_trace_range(ctx, "device", key.c_str(), b.ptr, bytes ? bytes : 16);
     ctx->tables[key] = b;
     return b.ptr;
 }
@@ -232,7 +296,7 @@ int uwip_prof_flush(uwip_ctx *ctx)
 
 UWIP_API int uwip_prof_enable(uwip_ctx *ctx, int on)
 {
-    if (!ctx) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     int rc = uwip_prof_flush(ctx);
     ctx->prof = on != 0;
     return rc;
@@ -240,7 +304,7 @@ UWIP_API int uwip_prof_enable(uwip_ctx *ctx, int on)
 
 UWIP_API int uwip_prof_reset(uwip_ctx *ctx)
 {
-    if (!ctx) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     int rc = uwip_prof_flush(ctx);
     ctx->prof_recs.clear();
     ctx->prof_index.clear();
@@ -250,6 +314,7 @@ UWIP_API int uwip_prof_reset(uwip_ctx *ctx)
 UWIP_API int uwip_prof_count(uwip_ctx *ctx, int *n)
 {
     if (!ctx || !n) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     int rc = uwip_prof_flush(ctx);
     *n = (int)ctx->prof_recs.size();
     return rc;
@@ -258,7 +323,7 @@ UWIP_API int uwip_prof_count(uwip_ctx *ctx, int *n)
 UWIP_API int uwip_prof_get(uwip_ctx *ctx, int index, char *name, size_t name_cap,
                            double *total_ms, uint64_t *launches)
 {
-    if (!ctx) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     if (index < 0 || index >= (int)ctx->prof_recs.size()) return ctx->fail(UWIP_ERR_INVALID, "prof index out of range");
     const uwip_prof_rec &r = ctx->prof_recs[index];
     if (name && name_cap) {

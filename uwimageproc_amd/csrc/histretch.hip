@@ -401,7 +401,7 @@ UWIP_API int uwip_getHistogram(uwip_ctx *ctx, const uwip_batch_u8 *img, uint32_t
 UWIP_API int uwip_stretch_lut(uwip_ctx *ctx, const uint32_t *d_hist, int nplanes, int rows, int cols,
                               int lo, int hi, uint8_t *d_lut, int32_t *d_bounds)
 {
-    if (!ctx) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     UWIP_REQUIRE(ctx, nplanes >= 0 && rows >= 0 && cols >= 0, "negative extent");
     if (nplanes == 0) return UWIP_OK;
     UWIP_REQUIRE(ctx, d_hist && d_lut, "null buffer");

@@ -1395,6 +1395,7 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
 UWIP_API int uwip_features_create(uwip_ctx *ctx, int max_frames, uwip_features **out)
 {
     if (!ctx || !out) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     UWIP_REQUIRE(ctx, max_frames >= 1 && max_frames <= 4096, "max_frames must be in [1,4096]");
     uwip_features *f = new (std::nothrow) uwip_features();
     if (!f) return UWIP_ERR_NOMEM;
@@ -1407,6 +1408,10 @@ UWIP_API int uwip_features_create(uwip_ctx *ctx, int max_frames, uwip_features *
         delete f;
         return ctx->fail(UWIP_ERR_NOMEM, "feature set hipMalloc");
     }
+    uwip_trace_range(ctx, "device", "features.kp", f->d_kp, K * sizeof(Keypoint));
+    uwip_trace_range(ctx, "device", "features.desc", f->d_desc, K * DESC_BYTES);
+    uwip_trace_range(ctx, "device", "features.bits", f->d_bits, K * DESC_K);
+    uwip_trace_range(ctx, "device", "features.pop", f->d_pop, K * sizeof(int32_t));
     (void)hipMemsetAsync(f->d_n, 0, sizeof(int32_t) * max_frames, ctx->stream);
     (void)hipMemsetAsync(f->d_bits, 0, K * DESC_K, ctx->stream);
     (void)hipMemsetAsync(f->d_pop, 0, K * sizeof(int32_t), ctx->stream);
@@ -1417,6 +1422,7 @@ UWIP_API int uwip_features_create(uwip_ctx *ctx, int max_frames, uwip_features *
 UWIP_API int uwip_features_destroy(uwip_features *f)
 {
     if (!f) return UWIP_OK;
+    (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
     (void)hipFree(f->d_kp); (void)hipFree(f->d_desc); (void)hipFree(f->d_bits); (void)hipFree(f->d_pop); (void)hipFree(f->d_n);
     delete f;
@@ -1477,6 +1483,7 @@ UWIP_API int uwip_features_download(uwip_ctx *ctx, const uwip_features *feats, i
                                     uint8_t *h_desc /*[2048][64]*/, int32_t *h_count)
 {
     if (!ctx || !feats) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     UWIP_REQUIRE(ctx, slot >= 0 && slot < feats->capacity, "slot out of range");
     UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (h_count) UWIP_HIP(ctx, hipMemcpy(h_count, feats->d_n + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1485,11 +1492,62 @@ UWIP_API int uwip_features_download(uwip_ctx *ctx, const uwip_features *feats, i
     return UWIP_OK;
 }
 
+// The opposite direction: fill one slot from host keypoints / packed descriptors (the reference's `struct keyframe`
+// has public keypoints / descriptors members that a caller may fill itself, videostrip.hpp:62-68); also how the
+// matcher is measured on a full 2048 x 2048 descriptor set.  Rows >= count are zeroed.
+namespace {
+__global__ __launch_bounds__(256) void k_ov_unpack_desc(const uint8_t *__restrict__ desc, int count, int8_t *__restrict__ bits,
+                                                       int32_t *__restrict__ pop)
+{
+    const int k = blockIdx.x;                         // keypoint
+    const int t = threadIdx.x;                        // 2 bits per thread -> 512
+    const uint8_t *d = desc + (size_t)k * DESC_BYTES;
+    const bool live = k < count;
+    const int b0 = live ? (d[(2 * t) >> 3] >> ((2 * t) & 7)) & 1 : 0, b1 = live ? (d[(2 * t + 1) >> 3] >> ((2 * t + 1) & 7)) & 1 : 0;
+    bits[(size_t)k * DESC_K + 2 * t] = (int8_t)b0;
+    bits[(size_t)k * DESC_K + 2 * t + 1] = (int8_t)b1;
+    __shared__ int s_c[4];
+    int c = b0 + b1;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) c += __shfl_xor(c, sft, 64);
+    if ((t & 63) == 0) s_c[t >> 6] = c;
+    __syncthreads();
+    if (t == 0) pop[k] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+}  // namespace
+
+UWIP_API int uwip_features_upload(uwip_ctx *ctx, uwip_features *feats, int slot, int rows, int cols, const void *h_kps,
+                                  const uint8_t *h_desc, int32_t count)
+{
+    if (!ctx || !feats) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
+    UWIP_REQUIRE(ctx, feats->ctx == ctx, "feature set of another context");
+    UWIP_REQUIRE(ctx, slot >= 0 && slot < feats->capacity, "slot out of range");
+    UWIP_REQUIRE(ctx, count >= 0 && count <= MAXKP, "count out of range");
+    UWIP_REQUIRE(ctx, rows > 0 && cols > 0 && (feats->w == 0 || (feats->w == cols && feats->h == rows)), "working size mismatch");
+    UWIP_REQUIRE(ctx, count == 0 || (h_kps && h_desc), "null buffer");
+    feats->w = cols; feats->h = rows;
+    uint8_t *stage = (uint8_t *)uwip_ws(ctx, "ov.upload.desc", (size_t)MAXKP * DESC_BYTES);
+    if (!stage) return UWIP_ERR_NOMEM;
+    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (count) {
+        UWIP_HIP(ctx, hipMemcpy(stage, h_desc, (size_t)count * DESC_BYTES, hipMemcpyHostToDevice));
+        UWIP_HIP(ctx, hipMemcpy(feats->d_kp + (size_t)slot * MAXKP, h_kps, sizeof(Keypoint) * (size_t)count, hipMemcpyHostToDevice));
+        UWIP_HIP(ctx, hipMemcpy(feats->d_desc + (size_t)slot * MAXKP * DESC_BYTES, h_desc, (size_t)count * DESC_BYTES, hipMemcpyHostToDevice));
+    }
+    UWIP_HIP(ctx, hipMemcpy(feats->d_n + slot, &count, sizeof(int32_t), hipMemcpyHostToDevice));
+    k_ov_unpack_desc<<<MAXKP, 256, 0, ctx->stream>>>(stage, count, feats->d_bits + (size_t)slot * MAXKP * DESC_K,
+                                                     feats->d_pop + (size_t)slot * MAXKP);
+    UWIP_HIP(ctx, hipGetLastError());
+    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return UWIP_OK;
+}
+
 // scale-space tap for tests: level images of slot-0 work buffers after the last detect call
 UWIP_API int uwip_overlap_debug_level(uwip_ctx *ctx, int frame, int level, int rows, int cols, float *h_Lt, float *h_Lx,
                                       float *h_Ly, float *h_Ldet, float *h_kcontrast)
 {
-    if (!ctx) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     UWIP_REQUIRE(ctx, level >= 0 && level < NLEV && frame >= 0, "bad level/frame");
     const size_t n = (size_t)rows * cols;
     auto get = [&](const char *name) -> float * {
@@ -1518,7 +1576,7 @@ UWIP_API int uwip_overlap_match(uwip_ctx *ctx, const uwip_features *fq, const uw
                                 const int32_t *h_pair_t, int npairs, int videoWidth, int videoHeight, uint32_t seed,
                                 float *d_ratio, int32_t *d_info, double *d_H, int32_t *d_match_idx, int32_t *d_match_dist)
 {
-    if (!ctx) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     UWIP_REQUIRE(ctx, fq && ft && fq->ctx == ctx && ft->ctx == ctx, "bad feature sets");
     UWIP_REQUIRE(ctx, npairs >= 0 && npairs <= 65535, "npairs out of range");
     if (npairs == 0) return UWIP_OK;
@@ -1559,7 +1617,7 @@ UWIP_API int uwip_overlap_match(uwip_ctx *ctx, const uwip_features *fq, const uw
 UWIP_API int uwip_overlapArea(uwip_ctx *ctx, const double *d_H, int n, int videoWidth, int videoHeight, float *d_ratio,
                               int32_t *d_count)
 {
-    if (!ctx) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     UWIP_REQUIRE(ctx, n >= 0, "negative count");
     if (n == 0) return UWIP_OK;
     UWIP_REQUIRE(ctx, d_H && d_ratio, "null buffer");
@@ -1601,7 +1659,7 @@ UWIP_API int uwip_calcBlur(uwip_ctx *ctx, const uwip_batch_u8 *frames, float *d_
 // keep a frame's cached keypoints/descriptors (what `struct keyframe` holds) in another slot
 UWIP_API int uwip_features_copy(uwip_ctx *ctx, const uwip_features *src, int src_slot, uwip_features *dst, int dst_slot)
 {
-    if (!ctx) return UWIP_ERR_INVALID;
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
     UWIP_REQUIRE(ctx, src && dst && src->ctx == ctx && dst->ctx == ctx, "bad feature sets");
     UWIP_REQUIRE(ctx, src_slot >= 0 && src_slot < src->capacity && dst_slot >= 0 && dst_slot < dst->capacity, "slot out of range");
     UWIP_REQUIRE(ctx, dst->w == 0 || (dst->w == src->w && dst->h == src->h), "feature sets of different working sizes");

@@ -58,6 +58,8 @@ void *uwip_host_ws(uwip_ctx *ctx, const char *name, size_t bytes);  // pinned ho
 const void *uwip_table_find(uwip_ctx *ctx, const std::string &key, size_t *bytes);
 const void *uwip_table_put(uwip_ctx *ctx, const std::string &key, const void *host, size_t bytes);
 int uwip_prof_flush(uwip_ctx *ctx);
+// UWIP_TRACE_ALLOC=1: report an allocation's address range on stderr (attributing a GPU fault address to a buffer)
+void uwip_trace_range(const uwip_ctx *ctx, const char *kind, const char *name, const void *p, size_t bytes);
 // clahe.hip: in-place 8-bit BGR -> HSV -> BGR (an HSV letter of histretch)
 int uwip_hsv_roundtrip(uwip_ctx *ctx, const uwip_batch_u8 *img);
 // winfilter15.hip: 15x15 window max and/or min of interleaved 3-channel u8 frames -> planar [F][3][H][W]
@@ -115,9 +117,20 @@ struct uwip_kscope {
     ~uwip_kscope();
 };
 
-static inline int uwip_check_batch(uwip_ctx *ctx, const uwip_batch_u8 *b, int channels /*0=any*/)
+// First statement of every entry point that allocates, copies or launches: makes the context's device the calling
+// thread's current one (hipSetDevice is thread-local state; a second host thread or a device != 0 would otherwise
+// hipMalloc / launch on whatever device that thread last used).
+static inline int uwip_enter(uwip_ctx *ctx)
 {
     if (!ctx) return UWIP_ERR_INVALID;
+    hipError_t e = hipSetDevice(ctx->device);
+    if (e != hipSuccess) return ctx->fail(UWIP_ERR_HIP, "hipSetDevice", hipGetErrorString(e));
+    return UWIP_OK;
+}
+
+static inline int uwip_check_batch(uwip_ctx *ctx, const uwip_batch_u8 *b, int channels /*0=any*/)
+{
+    if (int rc0 = uwip_enter(ctx)) return rc0;
     UWIP_REQUIRE(ctx, b != nullptr, "null batch");
     UWIP_REQUIRE(ctx, b->rows >= 0 && b->cols >= 0 && b->frames >= 0, "negative extent");
     UWIP_REQUIRE(ctx, b->channels == 1 || b->channels == 3, "channels must be 1 or 3");

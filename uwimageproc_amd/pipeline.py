@@ -90,6 +90,21 @@ class FramePipe:
         return ["bgdehaze(adaptiveExp_map,w=15)", "histretch(RGB,2/98)", "aclahe(V:sweep+select+CLAHE,HSV->BGR)",
                 "videostrip-overlap(frame vs predecessor: detect+describe+MFMA match+RANSAC+overlapArea)"]
 
+    # ---- host-buffer front end (GpuMat::upload ... download, histretch.cpp:174-175,212-213) ------------
+    def host_buffers(self):
+        """Page-locked input / output frame buffers [F,H,W,3] owned by the library."""
+        shape = (self.F, self.H, self.W, 3)
+        return self.ctx.host_alloc(shape), self.ctx.host_alloc(shape)
+
+    def run_host(self, h_in, h_out):
+        """upload -> the four stages -> download, all enqueued on the context's stream; `h_in` / `h_out`
+        come from ``host_buffers``.  Returns without waiting (``ctx.sync()`` drains the stream)."""
+        if getattr(self, "src_dev", None) is None:
+            self.src_dev = torch.empty((self.F, self.H, self.W, 3), dtype=torch.uint8, device=self.dev)
+        self.ctx.h2d_async(self.src_dev, h_in)
+        self.run(self.src_dev)
+        self.ctx.d2h_async(h_out, self.work)
+
     def run(self, src: torch.Tensor):
         self.stage_dehaze(src)
         self.stage_histretch()
