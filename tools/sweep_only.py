@@ -11,6 +11,8 @@ base = synth.uw_stream(0, 8, H, W)
 src = torch.from_numpy(np.concatenate([base] * 4)).cuda()
 pipe.stage_dehaze(src); pipe.stage_histretch()
 v = aclahe.bgr_to_v(pipe.ctx, pipe.work)
+if os.environ.get("SWEEP_RANDOM"):
+    v = torch.randint(0, 256, v.shape, dtype=torch.uint8, device=v.device)
 for _ in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
     aclahe.sweep(pipe.ctx, v)
 print("done")
