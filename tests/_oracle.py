@@ -73,6 +73,36 @@ class Oracle:
         L.orc_hsv_replace_v.restype = None
         L.orc_hsv_replace_v.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t, u8p, C.c_size_t]
 
+    # ---- bgdehaze in C (oracle/dehaze_oracle.c): the full-size checker and the CPU baseline ----
+    def dehaze(self, img, w=15, full=True, guard_s=False, B=None, taps=()):
+        """generate_results() for one uint8 BGR frame.  Returns (out_u8, dict of requested taps):
+        taps from {"B", "idx", "traw", "refined", "restored", "final"}."""
+        img = np.ascontiguousarray(img)
+        M, N = img.shape[:2]
+        out = np.zeros_like(img)
+        bufs = {"B": np.zeros(3), "idx": np.zeros(2, np.int32), "traw": np.zeros((2, M, N)), "refined": np.zeros((2, M, N)),
+                "restored": np.zeros((M, N, 3)), "final": np.zeros((M, N, 3))}
+        ptr = lambda k: bufs[k].ctypes.data_as(C.c_void_p) if k in taps else None
+        Bi = None if B is None else np.ascontiguousarray(B, np.float64)
+        f = self.lib.orc_dehaze_u8
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
+        rc = f(img.ctypes.data, M, N, img.strides[0], w, (1 if full else 0) | (2 if guard_s else 0),
+               None if Bi is None else Bi.ctypes.data, out.ctypes.data, out.strides[0],
+               ptr("B"), ptr("idx"), ptr("traw"), ptr("refined"), ptr("restored"), ptr("final"))
+        assert rc == 0, rc
+        return out, {k: bufs[k] for k in taps}
+
+    def guided_filter(self, guide, p, r=40, eps=1e-3):
+        guide, p = np.ascontiguousarray(guide, np.float64), np.ascontiguousarray(p, np.float64)
+        q = np.zeros_like(p)
+        f = self.lib.orc_guided_filter
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        rc = f(guide.ctypes.data, p.ctypes.data, p.shape[0], p.shape[1], r, eps, q.ctypes.data)
+        assert rc == 0, rc
+        return q
+
     def bgr_to_hsv_px(self, b, g, r):
         v = [C.c_int(0) for _ in range(3)]
         self.lib.orc_bgr_to_hsv_px(b, g, r, *[C.byref(x) for x in v])
@@ -217,6 +247,21 @@ class Oracle:
     def calcBlur(self, img):
         img = np.ascontiguousarray(img)
         return float(self.lib.orc_calcBlur(img, img.shape[0], img.shape[1], img.strides[0]))
+
+
+def assert_u8_differs_only_at_rounding_ties(got_u8, ref_float, eps=1e-6, what=""):
+    """`got_u8` must equal rint(clip(ref_float * 255)) except where ref_float * 255 sits within `eps` of a half-integer
+    (there a last-place difference between two float64 evaluation orders legitimately decides the rounding), and then by
+    one level at most.  Returns the number of such pixels."""
+    x = np.asarray(ref_float, np.float64) * 255.0
+    want = np.clip(np.rint(np.nan_to_num(x, nan=-1.0)), 0, 255).astype(np.int64)
+    d = np.asarray(got_u8).astype(np.int64) - want
+    bad = d != 0
+    if bad.any():
+        assert np.abs(d[bad]).max() <= 1, what
+        frac = np.abs(x[bad] - np.floor(x[bad]) - 0.5)
+        assert frac.max() <= eps, (what, float(frac.max()), int(bad.sum()))
+    return int(bad.sum())
 
 
 _cached = None

@@ -15,6 +15,7 @@ from uwimageproc_amd import bgdehaze as bg, synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import dehaze_oracle as dz  # noqa: E402
+import _oracle  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -114,10 +115,8 @@ def test_refined_t_and_restored_vs_reference_golden(ctx):
     assert np.abs(rt[0] - g["t_blue"]).max() <= TOL and np.abs(rt[1] - g["t_green"]).max() <= TOL
     restored = res["float"].cpu().numpy()[0]
     assert np.abs(restored - g["restored"]).max() <= TOL
-    u8 = res["out"].cpu().numpy()
-    exp = dz.to_u8(g["restored"])
-    diff = np.abs(u8.astype(int) - exp.astype(int))
-    assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3
+    # 8-bit output: equal to the rounded golden except where restored*255 sits on a rounding tie
+    _oracle.assert_u8_differs_only_at_rounding_ties(res["out"].cpu().numpy(), g["restored"])
 
 
 @pytest.mark.parametrize("shape,w", [((120, 160), 9), ((96, 128), 15), ((270, 480), 15)])
@@ -126,8 +125,7 @@ def test_rc_correction_end_to_end_vs_oracle(ctx, shape, w):
     exp_f = dz.RC_correction(dz.normalize_input(img), w)
     res = bg.dehaze(ctx, _dev(img), w, full=False, want_float=True)
     assert np.abs(res["float"].cpu().numpy()[0] - exp_f).max() <= TOL
-    diff = np.abs(res["out"].cpu().numpy().astype(int) - dz.to_u8(exp_f).astype(int))
-    assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3
+    _oracle.assert_u8_differs_only_at_rounding_ties(res["out"].cpu().numpy(), exp_f)
 
 
 @pytest.mark.parametrize("shape,seed,guard", [((96, 128), 296, False), ((135, 240), 335, True), ((270, 480), 470, True),
@@ -147,21 +145,34 @@ def test_exposure_tail_in_isolation(ctx, shape, seed, guard):
         assert np.isnan(got).all() and res["out"].cpu().numpy().max() == 0
     else:
         assert np.abs(got - exp_f).max() <= TOL
-        diff = np.abs(res["out"].cpu().numpy().astype(int) - dz.to_u8(exp_f).astype(int))
-        assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3
+        _oracle.assert_u8_differs_only_at_rounding_ties(res["out"].cpu().numpy(), exp_f)
 
 
 @pytest.mark.parametrize("shape", [(96, 128), (270, 480)])
-def test_dehaze_full_end_to_end_vs_oracle(ctx, shape):
-    """Whole chain vs the oracle's whole chain (guarded S).  Stated tolerance for the
-    tail: 2e-3 abs on the float image, <= 1 LSB on the 8-bit image for >= 95 % of pixels
-    (see test_exposure_tail_in_isolation for why it is not 1e-9)."""
+def test_dehaze_full_end_to_end_vs_oracle(ctx, orc, shape):
+    """Whole chain vs the oracle's whole chain (guarded S).  The only ill-conditioned step is the TRUNCATING uint8
+    cast of restored*255 (BGDehaze.py:75-76): the linearly mapped red channel sits on integers routinely, so two
+    float64 evaluation orders may truncate a handful of pixels differently.  Asserted: the casts differ ONLY where
+    restored*255 is within 1e-6 of an integer; on identical input the tail agrees to 1e-9 and the 8-bit image differs
+    only at rounding ties; end to end the float image agrees to 1e-9 when no cast flipped and to 2e-3 otherwise."""
+    import _dehaze_check
     img = synth.uw_frame(200 + shape[0], *shape)
-    exp_f = dz.adaptiveExp_map(dz.normalize_input(img), 15, guard_s=True)
-    res = bg.dehaze(ctx, _dev(img), 15, full=True, want_float=True, guard_s=True)
-    assert np.abs(res["float"].cpu().numpy()[0] - exp_f).max() <= 2e-3
-    diff = np.abs(res["out"].cpu().numpy().astype(int) - dz.to_u8(exp_f).astype(int))
-    assert diff.max() <= 1 and (diff != 0).mean() <= 5e-2
+    rep, _ = _dehaze_check.check_frame(ctx, orc, img, guard=True, what=str(shape))
+    print(shape, rep)
+
+
+@pytest.mark.parametrize("shape,seed", [((1080, 1920), 400), ((1080, 1920), 401), ((2160, 3840), 402)])
+def test_dehaze_full_size_vs_oracle(ctx, orc, shape, seed):
+    """BASELINE's own sizes (1080p, one 4K frame) against the oracle: the fused fast paths that only full-size aligned
+    frames take in anger -- k_winfilter15, the 8-bit transmission table inside k_gf_ws_solve, the recovery fused into
+    k_gf_ws_final, XCD-contiguous block order, many row chunks and chains -- with B found and with B injected."""
+    import _dehaze_check
+    img = synth.uw_frame(seed, *shape)
+    rep, _ = _dehaze_check.check_frame(ctx, orc, img, guard=True, what=f"{shape} seed {seed}")
+    print(shape, seed, rep)
+    if shape[0] == 1080 and seed == 400:
+        rep2, _ = _dehaze_check.check_frame(ctx, orc, img, guard=True, B=[0.8, 0.7, 0.3], what="B injected")
+        print("B injected", rep2)
 
 
 def test_dehaze_batch_matches_single(ctx):

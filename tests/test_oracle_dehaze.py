@@ -81,3 +81,52 @@ def test_end_to_end_runs_and_is_8bit():
     g = _load("dehaze_a.npz")
     out = dz.bgdehaze_u8(g["img"], 15, full=True)
     assert out.dtype == np.uint8 and out.shape == g["img"].shape and out.max() == 255 and out.min() == 0
+
+
+# ---- the C restatement (oracle/dehaze_oracle.c): the full-size checker and bench.py's CPU baseline ----------------
+def test_c_oracle_matches_reference_goldens(orc):
+    """The same golden vectors (produced from the reference's own Python) pin the C form directly."""
+    g = _load("guided_filter.npz")
+    assert np.abs(orc.guided_filter(g["I"], g["p"], 40, 1e-3) - g["q"]).max() <= 1e-9
+    assert np.abs(orc.guided_filter(g["I"][:85, :83], g["p"][:85, :83], 20, 1e-2) - g["q_r20"]).max() <= 1e-9
+    ga = _load("dehaze_a.npz")
+    img, Bref = ga["img"], ga["B"]
+    out, t = orc.dehaze(img, 15, full=False, B=Bref, taps=("traw", "refined", "restored", "idx", "B"))
+    assert np.abs(t["traw"] - np.moveaxis(ga["t_raw"], 2, 0)).max() <= 1e-12
+    assert np.abs(t["refined"][0] - ga["t_blue"]).max() <= 1e-9 and np.abs(t["refined"][1] - ga["t_green"]).max() <= 1e-9
+    assert np.abs(t["restored"] - ga["restored"]).max() <= 1e-9
+    if int(ga["tie_counts"][0]) == 1 and int(ga["tie_counts"][1]) == 1:
+        _, t2 = orc.dehaze(img, 15, full=False, taps=("B",))
+        assert np.abs(t2["B"] - Bref).max() <= 1e-12
+
+
+@pytest.mark.parametrize("shape,seed", [((96, 130), 1), ((181, 245), 2)])
+def test_c_oracle_equals_numpy_oracle(orc, shape, seed):
+    from uwimageproc_amd import synth
+    img = synth.uw_stream(seed, 1, shape[0], shape[1])[0]
+    normI = dz.normalize_input(img)
+    B, (i0, i1) = dz.background_light(normI, 15)
+    out_c, t = orc.dehaze(img, 15, full=True, guard_s=True, taps=("B", "idx", "refined", "restored", "final"))
+    assert (int(t["idx"][0]), int(t["idx"][1])) == (i0, i1) and np.array_equal(t["B"], B)
+    tb, tg = dz.refined_t(normI, B)
+    assert np.abs(t["refined"][0] - tb).max() <= 1e-9 and np.abs(t["refined"][1] - tg).max() <= 1e-9
+    restored = dz.RC_correction(normI, 15, B=B)
+    assert np.abs(t["restored"] - restored).max() <= 1e-9
+    # the tail truncates restored*255 to uint8 (BGDehaze.py:75-76): feed it the C form's own `restored`
+    final = dz.adaptiveExp_tail(normI, t["restored"], guard_s=True)
+    assert np.abs(t["final"] - final).max() <= 1e-9
+    assert np.array_equal(out_c, dz.to_u8(final))
+    # RC only, as uint8
+    out_rc, _ = orc.dehaze(img, 15, full=False)
+    # the red channel is a linear map of 8-bit values, so restored * 255 lands on exact half-integers routinely
+    import _oracle
+    _oracle.assert_u8_differs_only_at_rounding_ties(out_rc, restored, what="RC output")
+
+
+def test_c_oracle_refuses_small_images(orc):
+    import ctypes as C
+    img = np.zeros((80, 200, 3), np.uint8)
+    f = orc.lib.orc_dehaze_u8
+    f.restype = C.c_int
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
+    assert f(img.ctypes.data, 80, 200, 600, 15, 1, None, None, 0, None, None, None, None, None, None) == -2

@@ -108,9 +108,12 @@ def test_calcOverlap_end_to_end_and_known_translation(ctx, orc, stream):
         assert abs(r - er) <= 1e-6
         # ground truth: pure translation by j*(sx, sy)/3 working pixels
         tx, ty = j * sx / 3.0, j * sy / 3.0
-        true_ratio = (640 - tx) * (360 - ty) / (640 * 480 + 640 * 480 - (640 - tx) * (360 - ty))
         assert abs(H[0, 2] - tx) < 1.0 and abs(H[1, 2] - ty) < 1.0
-        assert r > 0
+        # overlapArea (videostrip.cpp:291-319) moves the 640 x 480 rectangle of its constants by H and counts what
+        # stays inside the 480 x 640 mask; ratio = ov / (videoWidth*videoHeight + area(quad) - ov) (SURVEY A-6)
+        ov = (640 - abs(tx)) * (480 - abs(ty))
+        true_ratio = ov / (640 * 480 + 640 * 480 - ov)
+        assert abs(r - true_ratio) <= 0.01, (j, r, true_ratio)      # the stated acceptance of the overlap ratio
     # as written (B-8): full-resolution area in the denominator -> ratio <= 0.148 for 1080p
     vs.videoWidth, vs.videoHeight = 1920, 1080
     r = vs.calcOverlap(ctx, kf, _dev(stream[1]))
