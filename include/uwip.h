@@ -189,6 +189,19 @@ int uwip_aclahe_select(const float *h_entropy, int frames, int32_t *h_bs, int32_
  * Synchronises the stream once (the choice is a host decision). */
 int uwip_aclahe_auto(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst,
                      int residual_rule, int32_t *h_bs, int32_t *h_cl);
+/* cv2.GaussianBlur(img, (3,3), 0) on 8UC1 planes, ACLAHE.py:15 (fixed [1 2 1]/4 kernel, BORDER_REFLECT_101; rounding of
+ * the /16: rule 0 = half up, OpenCV 3.4.x's 8-bit fixed-point path; rule 1 = half to even, OpenCV 3.2's float path).
+ * Not in place. */
+int uwip_GaussianBlur3(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int rounding_rule);
+/* The two forms of the aclahe stage the reference holds:
+ *   flags = 0                      the C++ driver, modules/aclahe/src/aclahe.cpp:152-187: the sweep runs on the plane itself
+ *                                  (= uwip_aclahe_auto);
+ *   flags = UWIP_ACLAHE_PREFILTER  ParametrosACLAHE, modules/aclahe/python/ACLAHE.py:9-129: the sweep (:40-47) and the
+ *                                  block-size search (:102-112) run on GaussianBlur(img,(3,3),0) (:15), the final
+ *                                  createCLAHE(CL,(BS,BS)).apply on the unfiltered image (python/main.py:19-20). */
+#define UWIP_ACLAHE_PREFILTER 1u
+int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst,
+                        int residual_rule, unsigned flags, int32_t *h_bs, int32_t *h_cl);
 
 /* "transform back image" (aclahe.cpp:216 stub): cvtColor(BGR2HSV), replace V by
  * v_new (the CLAHE'd plane), cvtColor(HSV2BGR), all 8-bit.  bgr_out may alias bgr. */

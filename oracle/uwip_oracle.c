@@ -407,6 +407,39 @@ ORC_API int orc_aclahe_sweep(const uint8_t *plane, int rows, int cols, size_t st
 /* point: (B*1868 + G*9617 + R*4899 + 8192) >> 14).  Used by            */
 /* modules/videostrip/src/videostrip.cpp:173,202.  parity unpinned.      */
 /* ------------------------------------------------------------------ */
+/* cv2.GaussianBlur(img, (3,3), 0) on an 8-bit plane (modules/aclahe/python/ACLAHE.py:15).  ksize 3 with sigma <= 0
+ * takes OpenCV's fixed table {0.25, 0.5, 0.25}; BORDER_DEFAULT = BORDER_REFLECT_101.  The separable passes are written
+ * out as OpenCV runs them: a horizontal pass into 8.8 fixed point (ufixedpoint16; exact, the taps are 64/256, 128/256),
+ * a vertical pass in the same format (still exact: 4 fractional bits used), and the cast to uchar that adds one half
+ * and truncates (rule 0, OpenCV 3.4.x).  rule 1 = the float separable filter of OpenCV 3.2, whose cvRound rounds an
+ * exact tie to even.  parity unpinned (OpenCV-internal). */
+static int orc_reflect101(int p, int n)
+{
+    if (n == 1) return 0;
+    if (p < 0) return -p;
+    if (p >= n) return 2 * (n - 1) - p;
+    return p;
+}
+ORC_API void orc_gaussian3_u8(const uint8_t *src, int rows, int cols, size_t step, uint8_t *dst, size_t dstep, int rule)
+{
+    uint16_t *h = (uint16_t *)malloc((size_t)rows * cols * sizeof(uint16_t));      /* 8.8 fixed point rows */
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const uint8_t *r = src + (size_t)y * step;
+            h[(size_t)y * cols + x] = (uint16_t)(64 * r[orc_reflect101(x - 1, cols)] + 128 * r[x] + 64 * r[orc_reflect101(x + 1, cols)]);
+        }
+    for (int y = 0; y < rows; ++y)
+        for (int x = 0; x < cols; ++x) {
+            const uint32_t a = h[(size_t)orc_reflect101(y - 1, rows) * cols + x], b = h[(size_t)y * cols + x],
+                           c = h[(size_t)orc_reflect101(y + 1, rows) * cols + x];
+            const uint32_t v = (64 * a + 128 * b + 64 * c) >> 8;      /* 8.8 again; the dropped bits are zero */
+            uint32_t q = (v + 128) >> 8;                              /* ufixedpoint16 -> uchar: half up */
+            if (rule == 1 && (v & 255) == 128) q = ((v >> 8) & 1) ? (v >> 8) + 1 : (v >> 8);
+            dst[(size_t)y * dstep + x] = (uint8_t)(q > 255 ? 255 : q);
+        }
+    free(h);
+}
+
 ORC_API void orc_bgr_to_gray(const uint8_t *bgr, int rows, int cols, size_t step,
                              uint8_t *gray, size_t gstep)
 {

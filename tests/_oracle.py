@@ -238,6 +238,15 @@ class Oracle:
         assert rc == 0
         return out.reshape(5, 51)
 
+    def gaussian3(self, plane, rule=0):
+        plane = np.ascontiguousarray(plane)
+        out = np.zeros_like(plane)
+        f = self.lib.orc_gaussian3_u8
+        f.restype = None
+        f.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t, C.c_int]
+        f(plane, plane.shape[0], plane.shape[1], plane.strides[0], out, out.strides[0], rule)
+        return out
+
     def bgr_to_gray(self, img):
         img = np.ascontiguousarray(img)
         g = np.zeros(img.shape[:2], np.uint8)

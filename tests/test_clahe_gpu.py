@@ -146,3 +146,35 @@ def test_aclahe_auto_matches_staged_path(ctx, orc):
         ebs, ecl = aclahe.select_parameters(orc.sweep(frames[f]))          # scipy mirror on the oracle's table
         assert (bs[f], cl[f]) == (ebs, ecl)
         assert np.array_equal(got[f], orc.clahe(frames[f], float(ecl), ebs, ebs))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 9), (7, 1), (37, 53), (270, 480), (1080, 1920)])
+@pytest.mark.parametrize("rule", [0, 1])
+def test_gaussian_blur3_vs_oracle(ctx, orc, shape, rule):
+    """cv2.GaussianBlur(img,(3,3),0), ACLAHE.py:15: bit-exact against the oracle (both rounding rules), batches, strides"""
+    rng = np.random.default_rng(shape[0] * 7 + shape[1])
+    a = rng.integers(0, 256, (3,) + shape, dtype=np.uint8)
+    a[1] = (a[1] // 64) * 2                      # few levels with many exact /16 ties
+    if shape[1] in (1, 3):                       # a [F, H, 1] tensor would read as H x W x C: one 2-D plane at a time
+        got = np.stack([aclahe.GaussianBlur3(ctx, torch.from_numpy(a[f]).cuda(), rule).cpu().numpy() for f in range(3)])
+    else:
+        got = aclahe.GaussianBlur3(ctx, torch.from_numpy(a).cuda(), rule).cpu().numpy()
+    for f in range(3):
+        assert np.array_equal(got[f], orc.gaussian3(a[f], rule)), (f, shape, rule)
+
+
+def test_aclahe_auto_python_and_cpp_driver_modes(ctx, orc):
+    """uwip_aclahe_auto_ex: ParametrosACLAHE (search on the blurred plane, final CLAHE on the plane itself) and the C++
+    driver's form (search on the plane) against the oracle driven the same way."""
+    from uwimageproc_amd import synth
+    frames = synth.uw_stream(3, 2, 216, 384)
+    v = np.stack([orc.bgr_to_v(f) for f in frames])
+    t = torch.from_numpy(v).cuda()
+    for prefilter in (True, False):
+        dst, params = aclahe.auto(ctx, t, prefilter=prefilter)
+        for f in range(2):
+            src = orc.gaussian3(v[f]) if prefilter else v[f]
+            bs, cl = aclahe.select_parameters(orc.sweep(src))
+            assert params[f] == (bs, cl), (prefilter, f, params[f], (bs, cl))
+            assert np.array_equal(dst[f].cpu().numpy(), orc.clahe(v[f], float(cl), bs, bs))     # final apply: unfiltered plane
+        assert aclahe.ParametrosACLAHE(ctx, t, prefilter=prefilter) == params

@@ -307,3 +307,44 @@ def test_hsv_known_values(orc):
     assert np.abs(rt.astype(int) - img.astype(int)).max() <= 3
     grey = np.repeat(img[..., :1], 3, axis=2)
     assert np.array_equal(orc.hsv_replace_v(grey, grey[..., 0]), grey)
+
+
+def test_gaussian3_known_answers(orc):
+    """cv2.GaussianBlur(img,(3,3),0) (ACLAHE.py:15): weights 1 2 1 / 2 4 2 / 1 2 1 over 16, BORDER_REFLECT_101."""
+    # a single bright pixel spreads as the kernel itself (255 * w / 16, rounded half up)
+    p = np.zeros((5, 5), np.uint8); p[2, 2] = 255
+    out = orc.gaussian3(p)
+    assert out[1:4, 1:4].tolist() == [[16, 32, 16], [32, 64, 32], [16, 32, 16]] and out.sum() == 256
+    # constant planes are fixed points; a ramp along x is preserved away from the borders
+    assert (orc.gaussian3(np.full((4, 7), 93, np.uint8)) == 93).all()
+    ramp = np.tile(np.arange(0, 40, 4, dtype=np.uint8), (3, 1))
+    assert np.array_equal(orc.gaussian3(ramp)[:, 1:-1], ramp[:, 1:-1])
+    # reflect-101 at the border: column -1 mirrors column 1 -> (2*a1 + 2*a0)/4 along x
+    assert orc.gaussian3(ramp)[0, 0] == (2 * 4 + 2 * 0 + 2) // 4
+    # rounding of an exact tie: sum = 8 (mod 16).  One pixel of value 8 in the centre: 8*4/16 = 2 exactly; value 2: 2*4/16 = 0.5
+    q = np.zeros((3, 3), np.uint8); q[1, 1] = 2
+    assert orc.gaussian3(q, rule=0)[1, 1] == 1 and orc.gaussian3(q, rule=1)[1, 1] == 0     # half up (3.4.x) vs half even (3.2)
+    q[1, 1] = 6                                                                             # 1.5 -> 2 either way
+    assert orc.gaussian3(q, rule=0)[1, 1] == 2 and orc.gaussian3(q, rule=1)[1, 1] == 2
+    # independent numpy restatement on random data, both rules, degenerate shapes
+    rng = np.random.default_rng(3)
+    for shape in [(1, 1), (1, 9), (7, 1), (2, 2), (37, 53)]:
+        a = rng.integers(0, 256, shape, dtype=np.uint8)
+        pad = np.pad(a.astype(np.int64), 1, mode="reflect") if min(shape) > 1 else None
+        if pad is None:
+            ry = [0] if shape[0] == 1 else None
+            idx_y = [0, 0, 0] if shape[0] == 1 else None
+            yy = np.array([0] * shape[0]) if shape[0] == 1 else np.arange(shape[0])
+            ref = lambda i, n: 0 if n == 1 else (-i if i < 0 else (2 * (n - 1) - i if i >= n else i))
+            s = np.zeros(shape, np.int64)
+            for y in range(shape[0]):
+                for x in range(shape[1]):
+                    for dy, wy in ((-1, 1), (0, 2), (1, 1)):
+                        for dx, wx in ((-1, 1), (0, 2), (1, 1)):
+                            s[y, x] += wy * wx * int(a[ref(y + dy, shape[0]), ref(x + dx, shape[1])])
+        else:
+            k = np.array([1, 2, 1])
+            s = sum(k[i] * k[j] * pad[i:i + shape[0], j:j + shape[1]] for i in range(3) for j in range(3))
+        up = (s + 8) >> 4
+        even = np.where((s & 15) == 8, ((s >> 4) + 1) & ~1, up)
+        assert np.array_equal(orc.gaussian3(a, 0), up.astype(np.uint8)) and np.array_equal(orc.gaussian3(a, 1), even.astype(np.uint8))

@@ -82,6 +82,8 @@ SIGNATURES = {
     "uwip_aclahe_knee": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
     "uwip_aclahe_select": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "uwip_aclahe_auto": (C.c_int, [_P, _B, _B, C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "uwip_aclahe_auto_ex": (C.c_int, [_P, _B, _B, C.c_int, C.c_uint, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "uwip_GaussianBlur3": (C.c_int, [_P, _B, _B, C.c_int]),
     "uwip_hsv_replace_v": (C.c_int, [_P, _B, _B, _B]),
     "uwip_dehaze_background_light": (C.c_int, [_P, _B, C.c_int, _P, _P]),
     "uwip_dehaze_transmission": (C.c_int, [_P, _B, _P, _P]),
@@ -111,6 +113,9 @@ def lib() -> C.CDLL:
                 f"{LIB_PATH} not found: build it with `make -C uwimageproc_amd/csrc` "
                 "(or __graft_entry__.build()); there is no CPU fallback"
             )
+        # torch first: it brings its own HIP runtime (torch/lib/libamdhip64.so); loading libuwip.so before it would map
+        # /opt/rocm's copy as well, and with two runtimes in one process the second one finds no device
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)  # AttributeError if the .so is stale

@@ -78,6 +78,34 @@ def clahe_per_frame(ctx: Context, src: torch.Tensor, clipLimits, grids, dst: tor
     return dst
 
 
+def GaussianBlur3(ctx: Context, img: torch.Tensor, rounding_rule: int = 0) -> torch.Tensor:
+    """cv2.GaussianBlur(img, (3,3), 0) on 8-bit planes (ACLAHE.py:15)."""
+    dst = torch.empty_like(img)
+    sb, db = batch_of(img), batch_of(dst)
+    _pre(img)
+    ctx.call("uwip_GaussianBlur3", C.byref(sb), C.byref(db), int(rounding_rule))
+    ctx.sync()
+    return dst
+
+
+ACLAHE_PREFILTER = 1
+
+
+def auto(ctx: Context, src: torch.Tensor, dst: torch.Tensor = None, residual_rule: int = 0, prefilter: bool = True):
+    """The whole aclahe stage on 8-bit planes: parameter search + final CLAHE.  prefilter=True is ParametrosACLAHE
+    (ACLAHE.py:9-129: search on the 3x3-blurred plane, final apply on the plane itself, python/main.py:19-20);
+    prefilter=False is the C++ driver's form (aclahe.cpp:152-187).  Returns (dst, [(BS, CL), ...])."""
+    if dst is None:
+        dst = torch.empty_like(src)
+    sb, db = batch_of(src), batch_of(dst)
+    n = sb.frames
+    bs, cl = (C.c_int32 * n)(), (C.c_int32 * n)()
+    _pre(src)
+    ctx.call("uwip_aclahe_auto_ex", C.byref(sb), C.byref(db), int(residual_rule), ACLAHE_PREFILTER if prefilter else 0, bs, cl)
+    ctx.sync()
+    return dst, list(zip(bs, cl))
+
+
 def aclaheEntropy(ctx: Context, img: torch.Tensor) -> torch.Tensor:
     """aclahe.cpp:228-248 per frame -> float32 [frames]."""
     b = batch_of(img)
@@ -165,8 +193,11 @@ def select_parameters(table, entropy_at=None):
     return BLOCK_SIZES[w], int(d)
 
 
-def ParametrosACLAHE(ctx: Context, imagen: torch.Tensor, residual_rule: int = 0):
-    """ACLAHE.py:9-129 for one 8-bit plane (or a batch): returns a list of (BS, CL)."""
+def ParametrosACLAHE(ctx: Context, imagen: torch.Tensor, residual_rule: int = 0, prefilter: bool = True):
+    """ACLAHE.py:9-129 for one 8-bit plane (or a batch): returns a list of (BS, CL).  The search runs on
+    imgfilt = GaussianBlur(imagen, (3,3), 0) (:15) unless prefilter=False (the C++ driver's unfiltered sweep)."""
+    if prefilter:
+        imagen = GaussianBlur3(ctx, imagen, residual_rule)
     tab = sweep(ctx, imagen, residual_rule).cpu().numpy()
     planes = imagen if imagen.dim() == 3 else imagen[None]
     out = []

@@ -119,6 +119,29 @@ __global__ __launch_bounds__(256) void k_bgr_to_v(const uint8_t *__restrict__ sr
     }
 }
 
+// ---- cv2.GaussianBlur(img, (3,3), 0) on an 8-bit plane (ACLAHE.py:15) ------------------------------------
+// ksize 3 with sigma <= 0 takes OpenCV's fixed table [0.25, 0.5, 0.25]; BORDER_DEFAULT = REFLECT_101.  Both passes are
+// exact in fixed point, so the result is (sum of the 3x3 window weighted 1 2 1 / 2 4 2 / 1 2 1) / 16 rounded:
+//   rule 0 (OpenCV 3.4.x, bit-exact 8-bit path: ufixedpoint16 -> uchar adds one half and truncates): round half UP
+//   rule 1 (OpenCV 3.2, float rows/columns + cvRound): round half to EVEN.   parity unpinned (OpenCV-internal).
+__global__ __launch_bounds__(256) void k_gauss3_u8(const uint8_t *__restrict__ src, size_t sstep, size_t sfs,
+                                                   uint8_t *__restrict__ dst, size_t dstep, size_t dfs, int rows, int cols, int rule)
+{
+    const int f = blockIdx.z, y = blockIdx.y;
+    const int ym = rows == 1 ? 0 : (y == 0 ? 1 : y - 1), yp = rows == 1 ? 0 : (y == rows - 1 ? rows - 2 : y + 1);
+    const uint8_t *r0 = src + (size_t)f * sfs + (size_t)ym * sstep, *r1 = src + (size_t)f * sfs + (size_t)y * sstep,
+                  *r2 = src + (size_t)f * sfs + (size_t)yp * sstep;
+    uint8_t *d = dst + (size_t)f * dfs + (size_t)y * dstep;
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < cols; x += gridDim.x * 256) {
+        const int xm = cols == 1 ? 0 : (x == 0 ? 1 : x - 1), xp = cols == 1 ? 0 : (x == cols - 1 ? cols - 2 : x + 1);
+        const int v0 = r0[xm] + 2 * r0[x] + r0[xp], v1 = r1[xm] + 2 * r1[x] + r1[xp], v2 = r2[xm] + 2 * r2[x] + r2[xp];
+        const int s = v0 + 2 * v1 + v2;                       // <= 16 * 255
+        int q = (s + 8) >> 4;                                  // half up
+        if (rule == 1 && (s & 15) == 8) q = ((s >> 4) & 1) ? (s >> 4) + 1 : (s >> 4);      // tie -> even
+        d[x] = (uint8_t)q;
+    }
+}
+
 // ---- C1a: tile histograms ---------------------------------------------------
 __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restrict__ src,
                                                         size_t step, size_t fstride, int rows,
@@ -648,6 +671,21 @@ UWIP_API int uwip_bgr_to_v(uwip_ctx *ctx, const uwip_batch_u8 *bgr, const uwip_b
     return UWIP_OK;
 }
 
+UWIP_API int uwip_GaussianBlur3(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int rounding_rule)
+{
+    int rc = check_pair(ctx, src, dst);
+    if (rc) return rc;
+    if (uwip_batch_empty(src)) return UWIP_OK;
+    UWIP_REQUIRE(ctx, src->data != dst->data, "GaussianBlur3 cannot run in place");
+    UWIP_REQUIRE(ctx, src->frames <= 65535 && src->rows <= 65535, "batch too large for one launch");
+    uwip_kscope ks(ctx, "k_gauss3_u8");
+    const dim3 grid(std::min(uwip_cdiv(src->cols, 256), 64u), (unsigned)src->rows, (unsigned)src->frames);
+    k_gauss3_u8<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, (uint8_t *)dst->data, dst->step,
+                                              dst->frame_stride, src->rows, src->cols, rounding_rule);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}
+
 UWIP_API int uwip_clahe_luts(uwip_ctx *ctx, const uwip_batch_u8 *src, double clipLimit, int gx, int gy,
                              int residual_rule, uint8_t *d_luts)
 {
@@ -856,14 +894,27 @@ int uwip_aclahe_select_internal(const float *h_entropy, int frames, int32_t *h_b
 
 // C3 + C4 + the final apply in one call: sweep -> (host) parameter choice -> per-frame CLAHE.
 // This is the whole "aclahe" stage of the pipe.  h_bs / h_cl receive the chosen parameters.
-UWIP_API int uwip_aclahe_auto(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int residual_rule,
-                              int32_t *h_bs, int32_t *h_cl)
+UWIP_API int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const uwip_batch_u8 *dst, int residual_rule, unsigned flags,
+                                 int32_t *h_bs, int32_t *h_cl)
 {
-    int rc = check_pair(ctx, src, dst);
+    int rc = check_pair(ctx, img, dst);
     if (rc) return rc;
-    if (src->frames == 0) return UWIP_OK;
-    UWIP_REQUIRE(ctx, !uwip_batch_empty(src), "aclahe of an empty image");
-    const int F = src->frames;
+    if (img->frames == 0) return UWIP_OK;
+    UWIP_REQUIRE(ctx, !uwip_batch_empty(img), "aclahe of an empty image");
+    UWIP_REQUIRE(ctx, (flags & ~(unsigned)UWIP_ACLAHE_PREFILTER) == 0, "unknown flag");
+    const int F = img->frames;
+    // ParametrosACLAHE searches its parameters on imgfilt = GaussianBlur(img, (3,3), 0) (ACLAHE.py:15: the sweep :40-47 and
+    // the block-size search :102-112 both run on it); the final createCLAHE(CL,(BS,BS)).apply takes the unfiltered image
+    // (python/main.py:19-20).  The C++ driver (aclahe.cpp:152-187) sweeps the unfiltered plane: flags = 0.
+    uwip_batch_u8 filt = *img;
+    if (flags & UWIP_ACLAHE_PREFILTER) {
+        uint8_t *fb = (uint8_t *)uwip_ws(ctx, "auto.blur", (size_t)img->rows * img->cols * F);
+        if (!fb) return UWIP_ERR_NOMEM;
+        filt.data = fb; filt.step = (size_t)img->cols; filt.frame_stride = (size_t)img->rows * img->cols;
+        rc = uwip_GaussianBlur3(ctx, img, &filt, residual_rule);
+        if (rc) return rc;
+    }
+    const uwip_batch_u8 *src = &filt;
     float *d_ent = (float *)uwip_ws(ctx, "auto.entropy", sizeof(float) * 255 * F);
     float *h_ent = (float *)uwip_host_ws(ctx, "auto.entropy", sizeof(float) * 255 * F);
     int32_t *h_par = (int32_t *)uwip_host_ws(ctx, "auto.params", sizeof(int32_t) * 4 * F + sizeof(float) * 5 * F + sizeof(double) * F);
@@ -908,7 +959,13 @@ UWIP_API int uwip_aclahe_auto(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwi
     for (int f = 0; f < F; ++f) clip[f] = (double)cl[f];
     if (h_bs) for (int f = 0; f < F; ++f) h_bs[f] = bs[f];
     if (h_cl) for (int f = 0; f < F; ++f) h_cl[f] = cl[f];
-    return uwip_clahe_per_frame(ctx, src, dst, clip, bs, residual_rule);
+    return uwip_clahe_per_frame(ctx, img, dst, clip, bs, residual_rule);
+}
+
+UWIP_API int uwip_aclahe_auto(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int residual_rule,
+                              int32_t *h_bs, int32_t *h_cl)
+{
+    return uwip_aclahe_auto_ex(ctx, src, dst, residual_rule, 0u, h_bs, h_cl);
 }
 
 // ---- "transform back image" (aclahe.cpp:216): BGR -> HSV, V := CLAHE(V), HSV -> BGR -------------------

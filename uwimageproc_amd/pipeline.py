@@ -6,8 +6,9 @@ decision: the ACLAHE parameter choice (ACLAHE.py:66-129).
 Stage definitions (DESIGN.md "the pipe"):
   bgdehaze   main.py:14-20 / adaptiveExp_map (w = 15), S guarded (B-11)
   histretch  -c=RGB, percentiles 2/98 (histretch.cpp:154,217-254)
-  aclahe     V of HSV (aclahe.cpp:152-154) -> sweep (:160-193) -> parameter choice
-             (ACLAHE.py:66-129) -> CLAHE(CL,(BS,BS)) -> back to BGR (aclahe.cpp:216)
+  aclahe     V of HSV (aclahe.cpp:152-154) -> ParametrosACLAHE (ACLAHE.py:9-129: 3x3 Gaussian prefilter :15,
+             sweep = aclahe.cpp:160-193, parameter choice :66-129) -> CLAHE(CL,(BS,BS)) on the unfiltered V
+             (python/main.py:19-20) -> back to BGR (aclahe.cpp:216)
   overlap    calcOverlap of every frame against its predecessor (videostrip.cpp:192-289),
              the last frame's features carried into the next batch
 """
@@ -68,7 +69,8 @@ class FramePipe:
         wb, vb, ob = batch_of(self.work), batch_of(self.v), batch_of(self.v_out)
         self.ctx.call("uwip_bgr_to_v", C.byref(wb), C.byref(vb))
         # sweep -> host parameter choice (native MINPACK restatement) -> per-frame CLAHE
-        self.ctx.call("uwip_aclahe_auto", C.byref(vb), C.byref(ob), 0, self.h_bs, self.h_cl)
+        # ParametrosACLAHE: the search runs on the 3x3-blurred V (ACLAHE.py:15), the final CLAHE on V itself (main.py:19-20)
+        self.ctx.call("uwip_aclahe_auto_ex", C.byref(vb), C.byref(ob), 0, 1, self.h_bs, self.h_cl)
         self.params = list(zip(self.h_bs, self.h_cl))
         self.ctx.call("uwip_hsv_replace_v", C.byref(wb), C.byref(ob), C.byref(wb))
 
@@ -87,7 +89,7 @@ class FramePipe:
                       self.seed, C.c_void_p(self.ratio.data_ptr()), C.c_void_p(self.info.data_ptr()), None, None, None)
 
     def stages(self):
-        return ["bgdehaze(adaptiveExp_map,w=15)", "histretch(RGB,2/98)", "aclahe(V:sweep+select+CLAHE,HSV->BGR)",
+        return ["bgdehaze(adaptiveExp_map,w=15)", "histretch(RGB,2/98)", "aclahe(V:blur3+sweep+select+CLAHE,HSV->BGR)",
                 "videostrip-overlap(frame vs predecessor: detect+describe+MFMA match+RANSAC+overlapArea)"]
 
     # ---- host-buffer front end (GpuMat::upload ... download, histretch.cpp:174-175,212-213) ------------
