@@ -32,16 +32,75 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step")
-    ap.add_argument("--rows", type=int, default=1080)
-    ap.add_argument("--cols", type=int, default=1920)
+    ap.add_argument("--config", choices=["1080p", "4k", "4k-paced"], default="1080p",
+                    help="1080p: BASELINE.json's metric (default); 4k: the same pipe on 3840x2160 frames (configs 3/5), 64 frames per "
+                         "step; 4k-paced: config 5's stream mode -- 600 frames arriving at 60 fps through host buffers, then unpaced")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 256 at 1080p, 64 at 4K)")
+    ap.add_argument("--rows", type=int, default=None)
+    ap.add_argument("--cols", type=int, default=None)
+    ap.add_argument("--paced-fps", type=float, default=60.0)
+    ap.add_argument("--paced-frames", type=int, default=600)
+    ap.add_argument("--paced-batch", type=int, default=4, help="frames gathered before the pipe runs (latency vs launch size)")
     ap.add_argument("--streams", type=int, default=4, help="independent sub-batches in flight per GPU (HIP streams + host threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matcher-bench", dest="matcher_bench", action="store_false",
                     help="skip the 2048 x 2048 matcher measurement (MFMA utilisation on BASELINE config 4's size)")
     ap.add_argument("--no-host-buffers", dest="host_buffers", action="store_false",
                     help="skip the upload/download-inclusive variant (timed on rank 0 after the main region)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    big = a.config != "1080p"
+    a.rows = a.rows or (2160 if big else 1080)
+    a.cols = a.cols or (3840 if big else 1920)
+    a.frames = a.frames or (64 if big else 256)
+    return a
+
+
+def synth_frames(n, H, W, seed0):
+    """n consecutive frames of the synthetic underwater stream, generated on the host cores in parallel"""
+    from concurrent.futures import ThreadPoolExecutor
+    from uwimageproc_amd import synth
+    chunk = 8
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        parts = list(ex.map(lambda k: synth.uw_stream(k * chunk, min(chunk, n - k * chunk), H, W, seed0=seed0), range((n + chunk - 1) // chunk)))
+    return np.concatenate(parts, axis=0)
+
+
+def paced_stream(args, dev_index, dev, H, W):
+    """BASELINE config 5's stream mode on this GPU: `paced_frames` frames of HxW arrive in page-locked host memory at
+    `paced_fps`; every `paced_batch` frames the pipe runs (upload -> four stages -> download, one stream, frame order kept
+    so the overlap chain is the stream's).  Reports the sustained rate and the worst arrival-to-result latency."""
+    from uwimageproc_amd.pipeline import FramePipe
+    B, n, fps = args.paced_batch, args.paced_frames, args.paced_fps
+    frames = synth_frames(max(B, 8), H, W, 4321)
+    st = torch.cuda.Stream(dev)
+    with torch.cuda.stream(st):
+        pipe = FramePipe(dev_index, B, H, W)
+    h_in, h_out = pipe.host_buffers()
+    for w in range(2):                                   # warm-up: workspaces, tables
+        h_in[...] = frames[:B]
+        pipe.run_host(h_in, h_out)
+        pipe.ctx.sync()
+    t0 = time.perf_counter() + 0.05
+    lat, finish = [], t0
+    for k in range(0, n - n % B, B):
+        arrive_last = t0 + (k + B - 1) / fps
+        now = time.perf_counter()
+        if now < arrive_last:
+            time.sleep(arrive_last - now)                # the batch is complete when its last frame has arrived
+        for j in range(B):
+            h_in[j] = frames[(k + j) % len(frames)]      # the "camera" writes into the pinned ring
+        pipe.run_host(h_in, h_out)
+        pipe.ctx.sync()
+        finish = time.perf_counter()
+        lat += [finish - (t0 + (k + j) / fps) for j in range(B)]
+    done = len(lat)
+    for a in (h_in, h_out):
+        pipe.ctx.host_free(a)
+    pipe.close()
+    return {"frames": done, "arrival_fps": fps, "batch": B, "sustained_fps": done / (finish - t0),
+            "keeps_up": bool(max(lat) < (B / fps) * 2 + 0.25), "worst_latency_ms": max(lat) * 1e3,
+            "median_latency_ms": float(np.median(lat)) * 1e3,
+            "note": "latency = result downloaded - frame arrival; a frame waits for its batch to fill, then for upload + pipe + download"}
 
 
 def cpu_baseline(H, W):
@@ -365,11 +424,14 @@ def main():
     S = max(1, args.streams)
     assert F % S == 0, "--frames must be divisible by --streams"
     Fs = F // S
-    # a few distinct synthetic frames, tiled to the batch (seed = 1234 + index)
-    distinct = min(F, 8)
-    base = synth.uw_stream(0, distinct, H, W, seed0=1234 + 1000 * rank)      # a different scene per rank, same size
-    reps = (F + distinct - 1) // distinct
-    src = torch.from_numpy(np.concatenate([base] * reps, axis=0)[:F]).to(dev)
+    # one sub-batch worth of DISTINCT consecutive frames of the synthetic stream (seed = 1234 + index), the
+    # same ones for every sub-batch: every launch works on Fs different images
+    distinct = min(Fs, 64)
+    base = synth_frames(distinct, H, W, 1234 + 1000 * rank)                  # a different scene per rank, same size
+    reps = (Fs + distinct - 1) // distinct
+    one = np.concatenate([base] * reps, axis=0)[:Fs]
+    src = torch.from_numpy(np.concatenate([one] * S, axis=0)).to(dev)
+    del one, base
     torch.cuda.synchronize()
     # S independent pipes, each on its own HIP stream and driven by its own host thread: frames are independent
     # units, so the HBM-bound dehaze passes of one half-batch overlap the LDS-bound sweep and the host-side
@@ -457,13 +519,19 @@ def main():
     if rank == 0:
         roof, kernels = roofline_report(args, pipe, parts[0], dev, F, Fs, H, W)
 
+    paced = None
+    if args.config == "4k-paced" and world == 1:
+        for pp in pipes:
+            pp.close()
+        paced = paced_stream(args, dev_index, dev, H, W)
     if rank == 0:
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(H, W)
         total_frames = world * F * args.steps
         line = {
-            "metric": "frames/sec whole-node, 1080p full pipe (dehaze+stretch+CLAHE+overlap)",
+            "metric": "frames/sec whole-node, 1080p full pipe (dehaze+stretch+CLAHE+overlap)" if (H, W) == (1080, 1920)
+                      else f"frames/sec whole-node, {W}x{H} full pipe (dehaze+stretch+CLAHE+overlap)",
             "value": total_frames / dt,
             "unit": "frames/s",
             "n_gpus": world,
@@ -476,12 +544,14 @@ def main():
             "vs_baseline": None,
             "dtype": "u8 (histretch/CLAHE), f64 (dehaze), f32+i8 (overlap)",
             "data": "synthetic",
-            "config": {"workload": f"full pipe bgdehaze->histretch->aclahe->videostrip-overlap on {W}x{H} uchar3 frames",
+            "config": {"name": args.config,
+                       "workload": f"full pipe bgdehaze->histretch->aclahe->videostrip-overlap on {W}x{H} uchar3 frames",
                        "frames_per_gpu_per_step": F, "streams_per_gpu": S, "stages": pipe.stages(),
                        "parallelism": f"frame-batch x{world}"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "host_buffers": host,
+            "paced_stream": paced,
             "kernels": kernels,
         }
         print(json.dumps(line))

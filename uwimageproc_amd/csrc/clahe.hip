@@ -259,6 +259,15 @@ __global__ __launch_bounds__(256) void k_clahe_pack(const uint8_t *__restrict__ 
 
 // ---- C1c: bilinear LUT interpolation, strip per block -------------------------
 // strips[s] = (cy, r0, r1, unused): rows [r0,r1) all have floor(y*inv_th-0.5)+1 == cy.
+// One launch may mix tile grids (the per-frame parameters of the aclahe stage): a per-frame descriptor then
+// replaces the launch-wide geometry, so that 64 frames stay ONE long launch instead of one short launch per grid size.
+struct ApplyFrame {
+    const int4 *strips;     // this frame's strip list
+    const uint8_t *packed;  // its packed LUT rows [(gy+1)][(gx+1)][256] uint32
+    int fr;                 // frame index in src / dst
+    int nstrips, gx, TX;
+    float inv_tw, inv_th;
+};
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__ src, size_t sstep,
                                                      size_t sfs, uint8_t *__restrict__ dst,
@@ -266,16 +275,23 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
                                                      int gy, float inv_tw, float inv_th,
                                                      const uint8_t *__restrict__ luts,
                                                      size_t lut_fs, const int4 *__restrict__ strips,
-                                                     const int *__restrict__ frame_map, int TX)
+                                                     const int *__restrict__ frame_map, int TX,
+                                                     const ApplyFrame *__restrict__ desc)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_pack[];   // [(gx+1)][256]
     const int tid = threadIdx.x;
+    const int f = blockIdx.y;
+    int fr = frame_map ? frame_map[f] : f;
+    const uint8_t *lbase = luts + (size_t)f * lut_fs;
+    if (desc) {                                     // block-uniform
+        const ApplyFrame d = desc[f];
+        if ((int)blockIdx.x >= d.nstrips) return;
+        strips = d.strips; lbase = d.packed; fr = d.fr; gx = d.gx; TX = d.TX; inv_tw = d.inv_tw; inv_th = d.inv_th;
+    }
     const int4 sd = strips[blockIdx.x];
     const int cy = sd.x, r0 = sd.y, r1 = sd.z;
-    const int f = blockIdx.y;
-    const int fr = frame_map ? frame_map[f] : f;
     // the packed LUT row of this strip's cell row: (gx+1)*256 uint32, pre-packed by k_clahe_pack
-    const uint4 *P4 = reinterpret_cast<const uint4 *>(luts + (size_t)f * lut_fs + (size_t)cy * (gx + 1) * 1024);
+    const uint4 *P4 = reinterpret_cast<const uint4 *>(lbase + (size_t)cy * (gx + 1) * 1024);
     for (int idx = tid; idx < (gx + 1) * 64; idx += 256) reinterpret_cast<uint4 *>(s_pack)[idx] = P4[idx];
     (void)gy;
     __syncthreads();
@@ -325,13 +341,11 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
                 for (int i = 0; i < 8; ++i) {
                     const uint32_t v = (w[u][i >> 2] >> ((i & 3) * 8)) & 255u;
                     const uint32_t p = s_pack[base[i] + v];
-                    // (TL*xa1 + TR*xa)*ya1 + (BL*xa1 + BR*xa)*ya with the two rows in one packed-f32 lane pair:
-                    // same products, sums and order as the scalar form (no FMA: -ffp-contract=off)
-                    const f32x2 ac = {(float)(p & 255u), (float)((p >> 16) & 255u)};
-                    const f32x2 bd = {(float)((p >> 8) & 255u), (float)(p >> 24)};
-                    const f32x2 xa1v = {xa1[i], xa1[i]}, xav = {xa[i], xa[i]}, yv = {ya1, ya};
-                    const f32x2 t = (ac * xa1v + bd * xav) * yv;
-                    const float res = t.x + t.y;
+                    // (TL*xa1 + TR*xa)*ya1 + (BL*xa1 + BR*xa)*ya, OpenCV's products, sums and order (no FMA: -ffp-contract=off)
+                    // plain f32 operations: on gfx950 a v_pk_mul/add_f32 costs 2.6x a v_mul/add_f32 (tools/ubench/valu_rate.hip)
+                    const float top = (float)(p & 255u) * xa1[i] + (float)((p >> 8) & 255u) * xa[i];
+                    const float bot = (float)((p >> 16) & 255u) * xa1[i] + (float)(p >> 24) * xa[i];
+                    const float res = top * ya1 + bot * ya;
                     // v_cvt_pk_u8_f32: round-to-nearest-even + clamp + byte insert in one instruction
                     o[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(res, i & 3, o[i >> 2]);
                 }
@@ -591,6 +605,23 @@ int build_strips(uwip_ctx *ctx, const ClaheGeom &g, int max_rows, const int4 **d
     return UWIP_OK;
 }
 
+int apply_tx(const ClaheGeom &g)
+{
+    const int groups = (g.cols + 7) / 8;
+    int TX = 256;
+    while (TX > 32 && TX / 2 >= groups) TX /= 2;
+    return TX;
+}
+
+// pack the LUTs of `nf` frames of one geometry into d_packed ([nf][(gy+1)][(gx+1)][256] uint32)
+int launch_pack(uwip_ctx *ctx, const ClaheGeom &g, const uint8_t *d_luts, size_t lut_fs, int nf, uint32_t *d_packed)
+{
+    uwip_kscope kp(ctx, "k_clahe_pack");
+    k_clahe_pack<<<dim3(g.gx + 1, g.gy + 1, nf), 256, 0, ctx->stream>>>(d_luts, lut_fs, g.gx, g.gy, d_packed);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}
+
 int launch_apply(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, const ClaheGeom &g,
                  const uint8_t *d_luts, size_t lut_fs, const int *d_frame_map, int nf)
 {
@@ -600,20 +631,15 @@ int launch_apply(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *d
     int rc = build_strips(ctx, g, max_rows, &d_strips, &nstrips);
     if (rc) return rc;
     if (nstrips == 0) return UWIP_OK;
-    const int groups = (g.cols + 7) / 8;
-    int TX = 256;
-    while (TX > 32 && TX / 2 >= groups) TX /= 2;
+    const int TX = apply_tx(g);
     const size_t lds = (size_t)(g.gx + 1) * 256 * sizeof(uint32_t);
     const bool vec = aligned_for(src, 8) && aligned_for(dst, 8);
     dim3 grid((unsigned)nstrips, (unsigned)nf);
     const size_t pack_fs = (size_t)(g.gy + 1) * (g.gx + 1) * 1024;      // bytes per frame
     uint32_t *d_packed = (uint32_t *)uwip_ws(ctx, "clahe.packed", pack_fs * nf);
     if (!d_packed) return UWIP_ERR_NOMEM;
-    {
-        uwip_kscope kp(ctx, "k_clahe_pack");
-        k_clahe_pack<<<dim3(g.gx + 1, g.gy + 1, nf), 256, 0, ctx->stream>>>(d_luts, lut_fs, g.gx, g.gy, d_packed);
-        UWIP_HIP(ctx, hipGetLastError());
-    }
+    rc = launch_pack(ctx, g, d_luts, lut_fs, nf, d_packed);
+    if (rc) return rc;
     d_luts = reinterpret_cast<const uint8_t *>(d_packed);
     lut_fs = pack_fs;
     uwip_kscope ks(ctx, "k_clahe_apply");
@@ -621,12 +647,33 @@ int launch_apply(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *d
         k_clahe_apply<true><<<grid, 256, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
                                                              (uint8_t *)dst->data, dst->step, dst->frame_stride, g.cols,
                                                              g.gx, g.gy, g.inv_tw, g.inv_th, d_luts, lut_fs, d_strips,
-                                                             d_frame_map, TX);
+                                                             d_frame_map, TX, nullptr);
     else
         k_clahe_apply<false><<<grid, 256, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
                                                               (uint8_t *)dst->data, dst->step, dst->frame_stride, g.cols,
                                                               g.gx, g.gy, g.inv_tw, g.inv_th, d_luts, lut_fs, d_strips,
-                                                              d_frame_map, TX);
+                                                              d_frame_map, TX, nullptr);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}
+
+// all frames of a batch in ONE launch, each with its own geometry (desc[f], device memory)
+int launch_apply_mixed(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, const ApplyFrame *d_desc, int nf,
+                       int max_strips, int max_gx)
+{
+    if (max_strips == 0 || nf == 0) return UWIP_OK;
+    const size_t lds = (size_t)(max_gx + 1) * 256 * sizeof(uint32_t);
+    const bool vec = aligned_for(src, 8) && aligned_for(dst, 8);
+    dim3 grid((unsigned)max_strips, (unsigned)nf);
+    uwip_kscope ks(ctx, "k_clahe_apply");
+    if (vec)
+        k_clahe_apply<true><<<grid, 256, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
+                                                             (uint8_t *)dst->data, dst->step, dst->frame_stride, src->cols, 0, 0,
+                                                             0.f, 0.f, nullptr, 0, nullptr, nullptr, 0, d_desc);
+    else
+        k_clahe_apply<false><<<grid, 256, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
+                                                              (uint8_t *)dst->data, dst->step, dst->frame_stride, src->cols, 0, 0,
+                                                              0.f, 0.f, nullptr, 0, nullptr, nullptr, 0, d_desc);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
@@ -742,22 +789,31 @@ UWIP_API int uwip_clahe_per_frame(uwip_ctx *ctx, const uwip_batch_u8 *src, const
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h_grid[a] < h_grid[b]; });
     int *h_map = (int *)uwip_host_ws(ctx, "clahe.pf.map", sizeof(int) * 2 * (size_t)F);
     int *d_map = (int *)uwip_ws(ctx, "clahe.pf.map", sizeof(int) * 2 * (size_t)F);
-    if (!h_map || !d_map) return UWIP_ERR_NOMEM;
+    ApplyFrame *h_desc = (ApplyFrame *)uwip_host_ws(ctx, "clahe.pf.desc", sizeof(ApplyFrame) * (size_t)F);
+    ApplyFrame *d_desc = (ApplyFrame *)uwip_ws(ctx, "clahe.pf.desc", sizeof(ApplyFrame) * (size_t)F);
+    if (!h_map || !d_map || !h_desc || !d_desc) return UWIP_ERR_NOMEM;
     UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int *h_clip = h_map + F, *d_clip = d_map + F;
+    size_t packed_bytes = 0;
     for (int i = 0; i < F; ++i) {
         const int f = order[i];
         h_map[i] = f;
         const ClaheGeom g = make_geom(src->rows, src->cols, h_grid[f], h_grid[f]);
         h_clip[i] = clip_from_limit(h_clipLimit[f], g.area);
+        packed_bytes += (size_t)(g.gy + 1) * (g.gx + 1) * 1024;
     }
     UWIP_HIP(ctx, hipMemcpyAsync(d_map, h_map, sizeof(int) * 2 * (size_t)F, hipMemcpyHostToDevice, ctx->stream));
     size_t max_tiles = 0;
     for (int f = 0; f < F; ++f) max_tiles = std::max(max_tiles, (size_t)h_grid[f] * h_grid[f]);
     uint32_t *d_hists = (uint32_t *)uwip_ws(ctx, "clahe.tilehist", sizeof(uint32_t) * 256 * max_tiles * F);
     uint8_t *d_luts = (uint8_t *)uwip_ws(ctx, "clahe.luts", (size_t)256 * max_tiles * F);
-    if (!d_hists || !d_luts) return UWIP_ERR_NOMEM;
-    int i = 0;
+    uint8_t *d_packed = (uint8_t *)uwip_ws(ctx, "clahe.packed", packed_bytes);
+    if (!d_hists || !d_luts || !d_packed) return UWIP_ERR_NOMEM;
+    // per group of equal grid size: tile histograms, LUTs, packed LUT rows (small launches); the interpolation itself
+    // then runs ONCE over all frames with a per-frame descriptor (a launch per group would be too short to reach the
+    // HBM rate: at 4K 16 frames split three ways ran at 29 % of peak, the single launch at 41 %)
+    int i = 0, max_strips = 0, max_gx = 0;
+    size_t poff = 0;
     while (i < F) {
         int j = i;
         const int gsz = h_grid[order[i]];
@@ -772,11 +828,26 @@ UWIP_API int uwip_clahe_per_frame(uwip_ctx *ctx, const uwip_batch_u8 *src, const
         rc = launch_lut(ctx, g, d_hists, cl, d_clip + i, nf, residual_rule, d_luts);
         if (rc) return rc;
         // d_hists / d_luts are reused by the next group: stream order keeps that safe
-        rc = launch_apply(ctx, src, dst, g, d_luts, (size_t)tiles * 256, d_map + i, nf);
+        const size_t pack_fs = (size_t)(g.gy + 1) * (g.gx + 1) * 1024;
+        rc = launch_pack(ctx, g, d_luts, (size_t)tiles * 256, nf, (uint32_t *)(d_packed + poff));
         if (rc) return rc;
+        const int4 *d_strips = nullptr;
+        int nstrips = 0;
+        rc = build_strips(ctx, g, 16, &d_strips, &nstrips);
+        if (rc) return rc;
+        for (int k = 0; k < nf; ++k) {
+            ApplyFrame &a = h_desc[i + k];
+            a.strips = d_strips; a.packed = d_packed + poff + (size_t)k * pack_fs; a.fr = order[i + k];
+            a.nstrips = nstrips; a.gx = g.gx; a.TX = apply_tx(g); a.inv_tw = g.inv_tw; a.inv_th = g.inv_th;
+        }
+        max_strips = std::max(max_strips, nstrips);
+        max_gx = std::max(max_gx, g.gx);
+        poff += pack_fs * nf;
         i = j;
     }
-    return UWIP_OK;
+    UWIP_HIP(ctx, hipMemcpyAsync(d_desc, h_desc, sizeof(ApplyFrame) * (size_t)F, hipMemcpyHostToDevice, ctx->stream));
+    // (two launches -- coarse grids with 9 KB of LDS, fine grids with 33 KB -- measured slower than this one: 99 vs 88 us at 4K)
+    return launch_apply_mixed(ctx, src, dst, d_desc, F, max_strips, max_gx);
 }
 
 UWIP_API int uwip_entropy(uwip_ctx *ctx, const uwip_batch_u8 *src, float *d_entropy)
