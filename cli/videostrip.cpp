@@ -14,41 +14,6 @@ static const int TARGET_WIDTH = 640;          // videostrip.hpp:48
 static const double OVERLAP_MIN = 0.4;        // videostrip.hpp:50
 static const int DEFAULT_KWINDOW = 11;        // videostrip.hpp:51
 
-// cv::resize(frame, res, Size(), f, f) for the blur metric: the library's own fixed-point resize is
-// internal to the detector, so the CLI keeps a host nearest/bilinear-free path: calcBlur is fed the frame
-// resized on the host with the same fixed-point bilinear arithmetic.
-static void resize_bilinear_u8(const imgio::Image &s, int oh, int ow, imgio::Image &d)
-{
-    d.rows = oh; d.cols = ow; d.channels = 3; d.data.resize((size_t)oh * ow * 3);
-    auto tab = [](int ssize, int dsize, std::vector<int> &ofs, std::vector<int> &c0, std::vector<int> &c1) {
-        ofs.resize(dsize); c0.resize(dsize); c1.resize(dsize);
-        const double scale = 1.0 / ((double)dsize / (double)ssize);
-        for (int i = 0; i < dsize; ++i) {
-            float fx = (float)((i + 0.5) * scale - 0.5);
-            int sx = (int)std::floor(fx);
-            fx -= (float)sx;
-            if (sx < 0) { fx = 0; sx = 0; }
-            if (sx >= ssize - 1) { fx = 0; sx = ssize - 1; }
-            ofs[i] = sx; c0[i] = (int)std::lrintf((1.f - fx) * 2048.f); c1[i] = (int)std::lrintf(fx * 2048.f);
-        }
-    };
-    std::vector<int> xo, xa, xb, yo, ya, yb;
-    tab(s.cols, ow, xo, xa, xb); tab(s.rows, oh, yo, ya, yb);
-    for (int y = 0; y < oh; ++y) {
-        const uint8_t *r0 = &s.data[(size_t)yo[y] * s.cols * 3];
-        const uint8_t *r1 = &s.data[(size_t)std::min(yo[y] + 1, s.rows - 1) * s.cols * 3];
-        for (int x = 0; x < ow; ++x) {
-            const int sx = xo[x], sx1 = std::min(sx + 1, s.cols - 1);
-            for (int c = 0; c < 3; ++c) {
-                const int S0 = r0[sx * 3 + c] * xa[x] + r0[sx1 * 3 + c] * xb[x];
-                const int S1 = r1[sx * 3 + c] * xa[x] + r1[sx1 * 3 + c] * xb[x];
-                const int v = (((ya[y] * (S0 >> 4)) >> 16) + ((yb[y] * (S1 >> 4)) >> 16) + 2) >> 2;
-                d.data[((size_t)y * ow + x) * 3 + c] = (uint8_t)std::min(std::max(v, 0), 255);
-            }
-        }
-    }
-}
-
 int main(int argc, char **argv)
 {
     const Args a = parse_args(argc, argv, {"k", "windowSize", "s", "timeSkip", "p", "minOverlap"});
@@ -73,13 +38,14 @@ int main(int argc, char **argv)
         uw::Context ctx(0);
         uw::Videostrip vsx(ctx);
         uw::keyframe kframe;
-        imgio::Image kimg, frame, bestframe, res;
+        imgio::Image kimg, frame, bestframe;
+        uw::Mat res;                              // res_frame: cv::resize(frame, res_frame, Size(), f, f), main.cpp:311
+        std::vector<uint8_t> res_store;
         int out_frame = 0, read_frames = 0;
         if (!read_frame(kimg)) { std::printf("Unable to read first frame\n"); return EXIT_FAILURE; }
         read_frames++;
         vsx.videoWidth = kimg.cols; vsx.videoHeight = kimg.rows;                          // main.cpp:238-239
         const float hResizeFactor = (float)TARGET_WIDTH / (float)kimg.cols;               // :242
-        const int ow = (int)std::lrint((double)kimg.cols * hResizeFactor), oh = (int)std::lrint((double)kimg.rows * hResizeFactor);
         std::printf("Video metadata:\n\tSize:\t%d x %d\n\tFrames:\t%zu\n\thResize:\t%g\nTarget minOverlap:\t%g\nWindow size:\t%d\n",
                     kimg.cols, kimg.rows, frames.size(), hResizeFactor, minOverlap, kWindow);
         report << "Video metadata:\n\tSize:\t" << kimg.cols << " x " << kimg.rows << "\n\tFrames:\t" << frames.size()
@@ -99,16 +65,16 @@ int main(int argc, char **argv)
             if (currOverlap == -2.0f) currOverlap = (float)(OVERLAP_MIN + 0.01);          // :321-326
             if (currOverlap <= minOverlap) {                                              // :329
                 std::printf("\n");
-                resize_bilinear_u8(frame, oh, ow, res);
-                float bestBlur = vsx.calcBlur(as_mat(res));                               // :338
+                vsx.resize(as_mat(frame), res, res_store);
+                float bestBlur = vsx.calcBlur(res);                                       // :338
                 int best_frame_number = (int)next - 1;
                 bestframe = frame;
                 bool eof = false;
                 for (int n = 0; n < kWindow; ++n) {                                       // :344-366
                     if (!read_frame(frame)) { eof = true; break; }
                     read_frames++;
-                    resize_bilinear_u8(frame, oh, ow, res);
-                    const float currBlur = vsx.calcBlur(as_mat(res));
+                    vsx.resize(as_mat(frame), res, res_store);
+                    const float currBlur = vsx.calcBlur(res);
                     std::printf("\rRefining search [%d/%d]\tBlur: %g\tBest: %g", n + 1, kWindow, currBlur, bestBlur);
                     if (currBlur > bestBlur) { bestBlur = currBlur; bestframe = frame; best_frame_number = read_frames; }
                 }

@@ -276,6 +276,9 @@ int uwip_features_copy(uwip_ctx *ctx, const uwip_features *src, int src_slot, uw
                        int dst_slot);
 /* working size for a rows x cols frame: cv::resize(frame, Size(), f, f), f = 640/cols */
 int uwip_overlap_working_size(int rows, int cols, int *orows, int *ocols);
+/* cv::resize(frame, res_frame, Size(), f, f) by itself (main.cpp:242,287,311; INTER_LINEAR, 8UC3 fixed point): the frame
+ * the reference hands to calcBlur (main.cpp:338,355).  dst: rows x cols of uwip_overlap_working_size. */
+int uwip_resize_bgr(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst);
 /* frames: full-resolution CV_8UC3 BGR (resized inside) or CV_8UC1 planes already at the
  * working size.  Fills slots [first_slot, first_slot + frames->frames). */
 int uwip_overlap_detect(uwip_ctx *ctx, const uwip_batch_u8 *frames, uwip_features *feats, int first_slot);

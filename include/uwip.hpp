@@ -160,6 +160,18 @@ public:
         if (r == -2.0f) std::printf("[WARN] Not enough good matches!\n");
         return r;
     }
+    // cv::resize(frame, res_frame, cv::Size(), hResizeFactor, hResizeFactor), main.cpp:242,287,311: `res` receives the
+    // 640-wide BGR frame (its buffer is (re)allocated into `store`)
+    void resize(const Mat &frame, Mat &res, std::vector<uint8_t> &store)
+    {
+        int oh = 0, ow = 0;
+        c_.check(uwip_overlap_working_size(frame.rows, frame.cols, &oh, &ow));
+        store.resize((size_t)oh * ow * 3);
+        res.data = store.data(); res.rows = oh; res.cols = ow; res.chans = 3; res.step = (size_t)ow * 3;
+        DeviceMat s(c_, frame), d(c_, oh, ow, 3);
+        c_.check(uwip_resize_bgr(c_.get(), s.batch(), d.batch()));
+        d.download(res);
+    }
     // float calcBlur(Mat frame): frame = the resized BGR frame (main.cpp:338,355)
     float calcBlur(const Mat &frame)
     {
@@ -184,5 +196,47 @@ private:
     uwip_features *obj_ = nullptr;
     void *scratch_ = nullptr;
 };
+
+// ---- the reference's own signatures, on a process-wide default context -------------------------------------
+// A call site of the reference switches by name alone (the `...GPU` twins of preprocessing.h:96 /
+// videostrip.hpp:84-118 are the precedent): same names, same argument order and defaults, the same globals
+// (videoWidth / videoHeight / hResizeFactor, main.cpp:45-49), cv::Mat replaced by the field-compatible uw::Mat.
+// Single-threaded, device 0, like the reference.
+namespace ref {
+inline Context &defaultContext() { static Context c(0); return c; }
+inline Videostrip &defaultVideostrip() { static Videostrip v(defaultContext()); return v; }
+inline int videoWidth = 0, videoHeight = 0;
+inline float hResizeFactor = 1.f;
+
+inline int numChannel(char c) { return uwip_numChannel(c); }                         // preprocessing.h:112
+inline int numSpace(char c) { return uwip_numSpace(c); }                             // preprocessing.h:115
+// void getHistogram(cv::Mat *imgOriginal, cv::Mat *histogram): the 256 x 1 CV_32F histogram as float[256]
+inline void getHistogram(Mat *imgOriginal, float histogram[256]) { uw::getHistogram(defaultContext(), *imgOriginal, histogram); }
+// void imgChannelStretch(cv::Mat imgOriginal, cv::Mat imgStretched, int lowerPercentile = 0, int higherPercentile = 100)
+inline void imgChannelStretch(Mat imgOriginal, Mat imgStretched, int lowerPercentile = 0, int higherPercentile = 100)
+{
+    uw::imgChannelStretch(defaultContext(), imgOriginal, imgStretched, lowerPercentile, higherPercentile, 0);
+}
+inline void imgChannelStretchGPU(Mat imgOriginal, Mat imgStretched, int lowerPercentile = 0, int higherPercentile = 100)
+{
+    imgChannelStretch(imgOriginal, imgStretched, lowerPercentile, higherPercentile);
+}
+// float calcOverlap(keyframe *kframe, cv::Mat img_object) / float calcBlur(cv::Mat frame) / float overlapArea(cv::Mat H)
+inline float calcOverlap(keyframe *kframe, Mat img_object)
+{
+    Videostrip &v = defaultVideostrip();
+    v.videoWidth = videoWidth; v.videoHeight = videoHeight;
+    return v.calcOverlap(kframe, img_object);
+}
+inline float calcOverlapGPU(keyframe *kframe, Mat img_object) { return calcOverlap(kframe, img_object); }
+inline float calcBlur(Mat frame) { return defaultVideostrip().calcBlur(frame); }
+inline float calcBlurGPU(Mat frame) { return calcBlur(frame); }
+inline float overlapArea(const double H[9])
+{
+    Videostrip &v = defaultVideostrip();
+    v.videoWidth = videoWidth; v.videoHeight = videoHeight;
+    return v.overlapArea(H);
+}
+}  // namespace ref
 
 }  // namespace uw

@@ -132,6 +132,15 @@ class Oracle:
         self.lib.orc_resize_gray(img, img.shape[0], img.shape[1], img.strides[0], oh, ow, g, None)
         return g
 
+    def resize_bgr(self, img):
+        """cv::resize(frame, res, Size(), f, f), f = 640 / cols: the 8UC3 frame calcBlur receives (main.cpp:311,338)"""
+        img = np.ascontiguousarray(img)
+        oh, ow = self.resize_dims(img.shape[0], img.shape[1])
+        g = np.zeros((oh, ow), np.uint8)
+        small = np.zeros((oh, ow, 3), np.uint8)
+        self.lib.orc_resize_gray(img, img.shape[0], img.shape[1], img.strides[0], oh, ow, g, small.ctypes.data)
+        return small
+
     def detect_describe(self, gray):
         gray = np.ascontiguousarray(gray)
         kps = np.zeros(2048, self.KP)

@@ -133,3 +133,26 @@ def test_videostrip_cli_selector_and_report(tmp_path, orc):
     c.close()
     assert len(rows) >= 2 and os.path.exists(prefix + "0000.png") and os.path.exists(prefix + f"{len(rows)-1:04d}.png")
     assert np.array_equal(_load_png(prefix + "0000.png"), frames[0])
+
+
+@pytest.mark.gpu
+def test_reference_signature_shims(tmp_path, orc):
+    """uw::ref::{calcOverlap, calcBlur, overlapArea, imgChannelStretch, getHistogram}: the reference's names, argument
+    order, defaults and globals on a default context (include/uwip.hpp), against the oracle."""
+    _build()
+    frames = synth.uw_stream(0, 2, 480, 640, step_frac=0.05)
+    a, b = str(tmp_path / "a.png"), str(tmp_path / "b.png")
+    _save_png(a, frames[0]); _save_png(b, frames[1])
+    r = subprocess.run([os.path.join(BIN, "refshim_check"), a, b], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    tok = r.stdout.split()
+    got = {tok[i]: tok[i + 1] for i in range(0, 10, 2)}
+    ov, _, _ = orc.calcOverlap(frames[0], frames[1], 640, 480, seed=1)
+    assert abs(float(got["overlap"]) - ov) <= 1e-5
+    assert abs(float(got["blur"]) - orc.calcBlur(frames[1])) <= 1e-3
+    assert abs(float(got["area"]) - 1.0) <= 1e-5
+    st = frames[1].copy()
+    orc.imgChannelStretch(st[:, :, 0], 2, 98)
+    assert int(got["stretch"]) == int(st.astype(np.uint64).sum())
+    assert float(got["hist0"]) == float((st[:, :, 0] == 0).sum())
+    assert tok[-2:] == ["1", "1"]

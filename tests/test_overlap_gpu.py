@@ -155,3 +155,38 @@ def test_calcBlur(ctx, orc):
     for f in range(3):
         assert abs(b[f] - orc.calcBlur(frames[f])) <= 1e-4
     assert vs.calcBlur(ctx, _dev(np.full((32, 32, 3), 9, np.uint8))) == 0.0
+
+
+def test_resize_bgr_and_selector_on_1080p(ctx, orc):
+    """cv::resize(frame, res, Size(), f, f) (main.cpp:311) bit-exact at 1080p, 4K and an odd size, and the Python
+    selector loop on full-resolution 1080p frames against the same loop driven by the oracle (the blur metric sees the
+    fixed-point 640-wide frame, not a float interpolation)."""
+    for shape in [(1080, 1920), (2160, 3840), (487, 731)]:
+        f = synth.uw_stream(3, 1, *shape)[0]
+        assert np.array_equal(vs.resize_bgr(ctx, _dev(f)).cpu().numpy(), orc.resize_bgr(f)), shape
+    n, k, p = 9, 2, 0.13
+    frames = synth.uw_stream(0, n, 1080, 1920, step_frac=0.04)
+    got = vs.select_keyframes(ctx, [_dev(f) for f in frames], minOverlap=p, kWindow=k)
+    exp = [(0, 0)]
+    key, nxt, read = frames[0], 1, 1
+    while nxt < n:
+        f = frames[nxt]; nxt += 1; read += 1
+        ov, _, _ = orc.calcOverlap(key, f, 1920, 1080, seed=1)       # as written: full-resolution area (B-8)
+        if ov == -2.0:
+            ov = 0.41
+        if ov <= p:
+            best, bestn, bf = orc.calcBlur(orc.resize_bgr(f)), nxt - 1, f
+            eof = False
+            for _ in range(k):
+                if nxt >= n:
+                    eof = True
+                    break
+                g = frames[nxt]; nxt += 1; read += 1
+                b = orc.calcBlur(orc.resize_bgr(g))
+                if b > best:
+                    best, bestn, bf = b, read, g
+            key = bf
+            exp.append((len(exp), bestn))
+            if eof:
+                break
+    assert [(a, b) for a, b, _, _ in got] == exp and len(exp) >= 2, (got, exp)

@@ -93,6 +93,7 @@ SIGNATURES = {
     "uwip_features_destroy": (C.c_int, [_P]),
     "uwip_features_copy": (C.c_int, [_P, _P, C.c_int, _P, C.c_int]),
     "uwip_overlap_working_size": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "uwip_resize_bgr": (C.c_int, [_P, _B, _B]),
     "uwip_overlap_detect": (C.c_int, [_P, _B, _P, C.c_int]),
     "uwip_features_download": (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(C.c_int32)]),
     "uwip_features_upload": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int32]),

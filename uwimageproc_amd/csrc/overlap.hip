@@ -93,6 +93,32 @@ __global__ __launch_bounds__(256) void k_ov_resize_gray(const uint8_t *__restric
     L0[o] = (float)g / 255.0f;
 }
 
+// cv::resize(frame, res_frame, Size(), f, f) alone (main.cpp:242,287,311): the 8UC3 result the reference hands to
+// calcOverlap and calcBlur.  Same fixed-point arithmetic as the fused kernel above.
+__global__ __launch_bounds__(256) void k_ov_resize_bgr(const uint8_t *__restrict__ src, size_t step, size_t fs, int rows, int cols,
+                                                      int oh, int ow, const int *__restrict__ xo, const short *__restrict__ xa,
+                                                      const short *__restrict__ xb, const int *__restrict__ yo,
+                                                      const short *__restrict__ ya, const short *__restrict__ yb,
+                                                      uint8_t *__restrict__ dst, size_t dstep, size_t dfs)
+{
+    const int f = blockIdx.z;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= ow || y >= oh) return;
+    const uint8_t *b = src + (size_t)f * fs;
+    const int sy = yo[y], sy1 = sy + 1 < rows ? sy + 1 : sy;
+    const uint8_t *r0 = b + (size_t)sy * step, *r1 = b + (size_t)sy1 * step;
+    const int sx = xo[x], sx1 = sx + 1 < cols ? sx + 1 : sx;
+    const int a0 = xa[x], a1 = xb[x], b0 = ya[y], b1 = yb[y];
+    uint8_t *o = dst + (size_t)f * dfs + (size_t)y * dstep + (size_t)x * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int S0 = r0[sx * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+        const int S1 = r1[sx * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+        const int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+        o[c] = (uint8_t)min(max(v, 0), 255);
+    }
+}
+
 // gray u8 (already at working size) -> L0
 __global__ void k_ov_gray_to_L0(const uint8_t *__restrict__ gray, float *__restrict__ L0, size_t n)
 {
@@ -1652,6 +1678,31 @@ UWIP_API int uwip_calcBlur(uwip_ctx *ctx, const uwip_batch_u8 *frames, float *d_
                                                               gray, L0);
     k_ov_blur<<<dim3(nb, F), 256, 0, ctx->stream>>>(gray, h, w, part);
     k_ov_blur_final<<<uwip_cdiv(F, 64), 64, 0, ctx->stream>>>(part, nb, (double)n, d_blur, F);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}
+
+// cv::resize(frame, res_frame, cv::Size(), hResizeFactor, hResizeFactor), main.cpp:242,287,311 (INTER_LINEAR, 8UC3):
+// dst must have the size uwip_overlap_working_size gives for src.
+UWIP_API int uwip_resize_bgr(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst)
+{
+    int rc = uwip_check_batch(ctx, src, 3);
+    if (rc) return rc;
+    rc = uwip_check_batch(ctx, dst, 3);
+    if (rc) return rc;
+    UWIP_REQUIRE(ctx, src->frames == dst->frames, "frame count mismatch");
+    if (src->frames == 0) return UWIP_OK;
+    UWIP_REQUIRE(ctx, !uwip_batch_empty(src), "empty image");
+    int oh = 0, ow = 0;
+    resize_dims(src->rows, src->cols, TW, &oh, &ow);
+    UWIP_REQUIRE(ctx, dst->rows == oh && dst->cols == ow, "dst is not the working size of src (uwip_overlap_working_size)");
+    const uint8_t *tx = (const uint8_t *)resize_table(ctx, src->cols, ow), *ty = (const uint8_t *)resize_table(ctx, src->rows, oh);
+    if (!tx || !ty) return UWIP_ERR_NOMEM;
+    uwip_kscope ks(ctx, "k_ov_resize_bgr");
+    k_ov_resize_bgr<<<grid2d(ow, oh, src->frames), 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, src->rows, src->cols, oh, ow,
+                                                                        (const int *)tx, (const short *)(tx + (size_t)ow * 4), (const short *)(tx + (size_t)ow * 6),
+                                                                        (const int *)ty, (const short *)(ty + (size_t)oh * 4), (const short *)(ty + (size_t)oh * 6),
+                                                                        (uint8_t *)dst->data, dst->step, dst->frame_stride);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }

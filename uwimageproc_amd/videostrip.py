@@ -117,6 +117,20 @@ def overlapArea(ctx: Context, H) -> float:
     return float(out.cpu()[0])
 
 
+def resize_bgr(ctx: Context, frame: torch.Tensor) -> torch.Tensor:
+    """cv::resize(frame, res, Size(), f, f) with f = 640 / cols (main.cpp:242,287,311): 8UC3 fixed-point bilinear."""
+    b = batch_of(frame)
+    oh, ow = C.c_int(0), C.c_int(0)
+    ctx._l.uwip_overlap_working_size(b.rows, b.cols, C.byref(oh), C.byref(ow))
+    shape = (b.frames, oh.value, ow.value, 3) if frame.dim() == 4 else (oh.value, ow.value, 3)
+    out = torch.empty(shape, dtype=torch.uint8, device=frame.device)
+    ob = batch_of(out)
+    torch.cuda.current_stream(frame.device).synchronize()
+    ctx.call("uwip_resize_bgr", C.byref(b), C.byref(ob))
+    ctx.sync()
+    return out
+
+
 def calcBlur(ctx: Context, frame: torch.Tensor):
     """videostrip.cpp:170-184 per BGR frame -> float (or a tensor for a batch)."""
     b = batch_of(frame)
@@ -142,12 +156,8 @@ def select_keyframes(ctx: Context, frames, minOverlap: float = OVERLAP_MIN, kWin
     h = int(round(videoHeight * (TARGET_WIDTH / videoWidth)))
     w = int(round(videoWidth * (TARGET_WIDTH / videoWidth)))
 
-    def resized(f):          # cv::resize(frame, res, Size(), f, f) only matters for calcBlur: identity when already 640 wide
-        if f.shape[1] == w and f.shape[0] == h:
-            return f
-        import torch.nn.functional as F_
-        t = F_.interpolate(f.permute(2, 0, 1)[None].float(), size=(h, w), mode="bilinear", align_corners=False)
-        return t[0].permute(1, 2, 0).round().clamp(0, 255).to(torch.uint8).contiguous()
+    def resized(f):          # cv::resize(frame, res_frame, Size(), f, f), main.cpp:311: what calcBlur receives (:338,355)
+        return resize_bgr(ctx, f)
 
     rows = [(0, 0, 0.0, 0.0)]
     kf = keyframe(ctx, frames[0])
