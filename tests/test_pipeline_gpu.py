@@ -220,3 +220,28 @@ def test_host_buffer_front_end_equals_device_path():
         for a in bufs[i]:
             pipes[i].ctx.host_free(a)
         pipes[i].close()
+
+
+def test_stream_driver_seam_rule_with_the_real_pipe():
+    """uwimageproc_amd.stream: two ranks' slices (run one after the other here, each with its own FramePipe) give frame
+    for frame the output, ratio and CLAHE parameters of the single-rank stream -- the one-frame halo makes the overlap
+    of a slice's first frame exact."""
+    from uwimageproc_amd import stream
+    n, B, H, W = 7, 3, 216, 384
+    frames = synth.uw_stream(0, n, H, W)
+    def run(rank, world):
+        pipe = FramePipe(0, B, H, W, video_size=(640, 480))
+        drv = stream.StreamDriver(n, rank, world, B, stream.pipe_process(pipe))
+        outs = {}
+        r, p = drv.run(lambda i: frames[i], sink=lambda i, f: outs.__setitem__(i, f.copy()))
+        pipe.close()
+        return drv, outs, r, p
+    _, o1, r1, p1 = run(0, 1)
+    got_o, got_r, got_p = {}, [], []
+    for rank in range(2):
+        drv, o, r, p = run(rank, 2)
+        assert sorted(o) == list(range(drv.start, drv.stop))
+        got_o.update(o); got_r += r; got_p += p
+    assert got_p == p1 and np.array_equal(np.array(got_r, np.float32), np.array(r1, np.float32))
+    for i in range(n):
+        assert np.array_equal(got_o[i], o1[i]), i
