@@ -1,8 +1,11 @@
 // histretch -- percentile histogram stretch of selected channels.
 // Flags and messages follow modules/histretch/src/histretch.cpp:61-272:
-//   histretch [-c=<letters>] [-cuda=0|1] [-time=0|1] <input> <output>
+//   histretch [-c=<letters>] [-cuda=0|1] [-time=0|1] [--fixed-order] <input> <output>
 // Differences, on purpose: headless (no imshow / waitKey), -time is optional
-// (B-4), and there is no CPU implementation in this build: -cuda=0 is refused.
+// (B-4), and there is no CPU implementation in this build: -cuda=0 is refused (BASELINE config 1, the
+// reference's OpenCV CPU path on one 640x480 PNG, is therefore exercised through the HIP path: tests/test_cli.py).
+// --fixed-order: letters of HSV / hsl / Lab / YCX keep their stretch (merge before converting back) instead of the
+// as-written round trip (B-3).
 #include "cliutil.hpp"
 
 int main(int argc, char **argv)
@@ -13,7 +16,8 @@ int main(int argc, char **argv)
         std::printf("C++ implementation of Histogram Stretching for specific channels of input image\n"
                     "usage: histretch [-c=<channels>] [-cuda=0|1] [-time=0|1] <input> <output>\n"
                     "Argument 'c=<channels>' is a string containing an ordered list of desired channels to be stretched\n"
-                    "\t-c=R|G|B\tfor RGB space (HSV/hsl/Lab/YCX letters are outside the accelerated path)\n"
+                    "\t-c=R|G|B\tfor RGB space\n\t-c=H|S|V\tfor HSV space\n\t-c=h|s|l\tfor hsl space\n\t-c=L|a|b\tfor Lab space\n"
+                    "\t-c=Y|C|X\tfor YCrCb space\n\t--fixed-order\tkeep the stretch of the non-RGB letters (the reference discards it)\n"
                     "\tExample:\n\t$ histretch -c=RGB input.png output.png -cuda=1 -time=1\n");
         return 0;
     }
@@ -36,7 +40,7 @@ int main(int argc, char **argv)
             if (uw::numSpace(cChannel[nc]) == -1) std::printf("Option %c not recognized, skipping...\n", cChannel[nc]);
         }
         Stopwatch sw;
-        uw::histretch(ctx, as_mat(src), cChannel, 2, 98);         // min_percent = 2, max_percent = 98 (histretch.cpp:154)
+        uw::histretch(ctx, as_mat(src), cChannel, 2, 98, a.has("fixed-order"));   // min_percent = 2, max_percent = 98 (histretch.cpp:154)
         if (Time == 1) std::printf("\nExecution Time GPU :%g ms \n", sw.ms());
     } catch (const uw::Error &e) {
         std::printf("error: %s\n", e.what());

@@ -135,12 +135,22 @@ int uwip_imgChannelStretch(uwip_ctx *ctx, const uwip_batch_u8 *img, int channel,
 
 /* The per-letter loop of histretch.cpp:217-254 on BGR frames, in place:
  * for each letter in order, stretch plane numChannel(letter).  Unknown
- * letters are skipped as the reference does.  HSV ('H','S','V') and YCrCb
- * ('Y','C','X') letters do what the reference's code does with them
- * (SURVEY.md B-3): the stretch lands in a split copy and the image receives
- * the 8-bit colour round trip cvtColor(BGR2xxx) -> cvtColor(xxx2BGR), applied
- * in letter order between the BGR letters' stretches.  HLS and Lab letters
- * return UWIP_ERR_UNSUPPORTED before anything is modified. */
+ * letters are skipped as the reference does.  Letters of the other colour
+ * spaces -- HSV ('H','S','V'), HLS ('h','s','l'), Lab ('L','a','b'), YCrCb
+ * ('Y','C','X') -- do what the reference's code does with them (SURVEY.md
+ * B-3): the stretch lands in a split copy and the image receives the 8-bit
+ * colour round trip cvtColor(BGR2xxx) -> cvtColor(xxx2BGR), applied in letter
+ * order between the BGR letters' stretches.
+ * uwip_histretch_ex with UWIP_HISTRETCH_FIXED_ORDER runs the evident intent
+ * instead: convert (histretch.cpp:232), split / stretch / MERGE (:234-236,
+ * :240), then convert back (:238) -- the stretch is kept.
+ * The 8-bit conversions restate OpenCV 3.x's color.cpp (parity unpinned). */
+#define UWIP_HISTRETCH_FIXED_ORDER 1u
+int uwip_histretch_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi,
+                      unsigned flags);
+/* cv::cvtColor(src, dst, COLOR_BGR2{HSV,HLS,Lab,YCrCb}) (to_bgr = 0) or COLOR_{..}2BGR (to_bgr = 1) on 8UC3 batches;
+ * space = uwip_numSpace's index 1..4 (histretch.cpp:155-156).  dst may alias src. */
+int uwip_cvtColor(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int space, int to_bgr);
 int uwip_histretch(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi);
 
 /* ---- aclahe (C1-C4) ----------------------------------------------------- */

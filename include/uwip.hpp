@@ -114,10 +114,10 @@ inline void imgChannelStretch(Context &c, Mat imgOriginal, Mat imgStretched, int
 }
 
 // the per-letter loop of histretch.cpp:217-254 on a BGR image, in place
-inline void histretch(Context &c, Mat src, const std::string &cChannel, int min_percent = 2, int max_percent = 98)
+inline void histretch(Context &c, Mat src, const std::string &cChannel, int min_percent = 2, int max_percent = 98, bool fixed_order = false)
 {
     DeviceMat d(c, src);
-    c.check(uwip_histretch(c.get(), d.batch(), cChannel.c_str(), min_percent, max_percent));
+    c.check(uwip_histretch_ex(c.get(), d.batch(), cChannel.c_str(), min_percent, max_percent, fixed_order ? UWIP_HISTRETCH_FIXED_ORDER : 0u));
     d.download(src);
 }
 

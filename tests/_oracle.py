@@ -212,6 +212,24 @@ class Oracle:
         rc = self.lib.orc_histretch_bgr(out, out.shape[0], out.shape[1], out.strides[0], letters.encode(), lo, hi)
         return out, rc
 
+    def cvt_space(self, img, space, to_bgr=False):
+        """cv::cvtColor BGR2{HSV,HLS,Lab,YCrCb} (space 1..4) or back, 8UC3 (oracle/uwip_oracle_color.c)"""
+        img = np.ascontiguousarray(img)
+        out = np.zeros_like(img)
+        f = self.lib.orc_cvt_space
+        f.restype = C.c_int
+        f.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_int]
+        assert f(img.reshape(-1), img.shape[0], img.shape[1], img.strides[0], out.reshape(-1), out.strides[0], space, 1 if to_bgr else 0) == 0
+        return out
+
+    def histretch_ex(self, img, letters, lo=2, hi=98, fixed_order=False):
+        out = np.ascontiguousarray(img).copy()
+        f = self.lib.orc_histretch_bgr_ex
+        f.restype = C.c_int
+        f.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int]
+        assert f(out.reshape(-1), out.shape[0], out.shape[1], out.strides[0], letters.encode(), lo, hi, 1 if fixed_order else 0) == 0
+        return out
+
     def imgChannelStretch(self, plane, lo, hi):
         """in place on a 2-D uint8 view"""
         self.lib.orc_imgChannelStretch(plane.ctypes.data, plane.shape[0], plane.shape[1], plane.strides[0], plane.strides[1], lo, hi)

@@ -124,15 +124,46 @@ def test_colour_space_letters_as_written(ctx, orc, letters, shape):
     assert np.array_equal(t.cpu().numpy(), exp)
 
 
+@pytest.mark.parametrize("space", [1, 2, 3, 4])
+def test_cvtColor_both_directions_vs_oracle(ctx, orc, space):
+    """cv::cvtColor BGR2{HSV,HLS,Lab,YCrCb} and back, 8UC3: bit-exact against the oracle's restatement (every 8-bit
+    colour of a dense random sample, a real-looking frame, strided batches)."""
+    rng = np.random.default_rng(space)
+    for img in (rng.integers(0, 256, (96, 128, 3), dtype=np.uint8), synth.uw_frame(4, 135, 241)):
+        fwd = pp.cvtColor(ctx, _dev(img), space).cpu().numpy()
+        assert np.array_equal(fwd, orc.cvt_space(img, space)), space
+        back = pp.cvtColor(ctx, _dev(fwd), space, to_bgr=True).cpu().numpy()
+        assert np.array_equal(back, orc.cvt_space(fwd, space, True)), space
+    batch = rng.integers(0, 256, (3, 40, 56, 3), dtype=np.uint8)
+    got = pp.cvtColor(ctx, _dev(batch), space).cpu().numpy()
+    for f in range(3):
+        assert np.array_equal(got[f], orc.cvt_space(batch[f], space))
+
+
+@pytest.mark.parametrize("letters", ["l", "h", "s", "L", "a", "b", "RlG", "LaV", "YhB"])
+@pytest.mark.parametrize("fixed", [False, True])
+def test_hls_lab_letters_and_fixed_order(ctx, orc, letters, fixed):
+    """hsl / Lab letters: as written they leave the 8-bit colour round trip (B-3); with the fixed-order
+    flag the stretch of the letter's plane is kept (convert, split / stretch / merge, convert back)."""
+    img = synth.uw_frame(21, 72, 100)
+    t = _dev(img)
+    pp.histretch(ctx, t, letters, fixed_order=fixed)
+    assert np.array_equal(t.cpu().numpy(), orc.histretch_ex(img, letters, fixed_order=fixed)), (letters, fixed)
+
+
+@pytest.mark.parametrize("letters", ["V", "HY", "RSC"])
+def test_fixed_order_hsv_ycrcb(ctx, orc, letters):
+    img = synth.uw_frame(22, 60, 84)
+    t = _dev(img)
+    pp.histretch(ctx, t, letters, fixed_order=True)
+    assert np.array_equal(t.cpu().numpy(), orc.histretch_ex(img, letters, fixed_order=True))
+
+
 def test_empty_and_errors(ctx):
     import uwimageproc_amd as uw
     e = torch.zeros((0, 8, 3), dtype=torch.uint8, device="cuda")
     pp.histretch(ctx, e, "RGB")            # empty input is a no-op
     img = _dev(synth.uw_frame(1, 16, 16))
-    before = img.clone()
-    with pytest.raises(uw.UwipError) as ei:
-        pp.histretch(ctx, img, "RL")       # HLS / Lab letters are not implemented: refused before anything is touched
-    assert ei.value.code == 3 and torch.equal(img, before)
     with pytest.raises(uw.UwipError):
         pp.imgChannelStretch(ctx, img, None, 2, 98, channel=5)
 

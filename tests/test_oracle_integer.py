@@ -348,3 +348,37 @@ def test_gaussian3_known_answers(orc):
         up = (s + 8) >> 4
         even = np.where((s & 15) == 8, ((s >> 4) + 1) & ~1, up)
         assert np.array_equal(orc.gaussian3(a, 0), up.astype(np.uint8)) and np.array_equal(orc.gaussian3(a, 1), even.astype(np.uint8))
+
+
+def test_colour_space_known_answers(orc):
+    """8-bit cvtColor restatements (oracle/uwip_oracle_color.c): the values OpenCV is known to give for the primaries,
+    white, black and mid grey.  parity unpinned beyond these."""
+    px = np.array([[[0, 0, 255], [0, 255, 0], [255, 0, 0], [255, 255, 255], [0, 0, 0], [128, 128, 128]]], np.uint8)   # BGR: red, green, blue, ...
+    lab = orc.cvt_space(px, 3)[0].tolist()
+    assert lab == [[136, 208, 195], [224, 42, 211], [82, 207, 20], [255, 128, 128], [0, 128, 128], [137, 128, 128]]
+    hls = orc.cvt_space(px, 2)[0].tolist()
+    assert hls == [[0, 128, 255], [60, 128, 255], [120, 128, 255], [0, 255, 0], [0, 0, 0], [0, 128, 0]]
+    ycc = orc.cvt_space(px, 4)[0].tolist()
+    assert ycc == [[76, 255, 85], [150, 21, 43], [29, 107, 255], [255, 128, 128], [0, 128, 128], [128, 128, 128]]
+    hsv = orc.cvt_space(px, 1)[0].tolist()
+    assert hsv == [[0, 255, 255], [60, 255, 255], [120, 255, 255], [0, 0, 255], [0, 0, 0], [0, 0, 128]]
+    # greys survive every round trip exactly; saturated colours within the 8-bit quantisation of each space
+    grey = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)
+    rng = np.random.default_rng(5)
+    rnd = rng.integers(0, 256, (32, 64, 3), dtype=np.uint8)
+    for sp, tol in ((1, 3), (2, 3), (3, 6), (4, 2)):
+        gd = np.abs(orc.cvt_space(orc.cvt_space(grey, sp), sp, True).astype(int) - grey.astype(int))
+        assert gd.max() <= (2 if sp == 3 else 0), sp        # 8-bit L (x 255/100) merges neighbouring dark greys
+        d = np.abs(orc.cvt_space(orc.cvt_space(rnd, sp), sp, True).astype(int) - rnd.astype(int))
+        assert d.max() <= 32 and np.percentile(d, 99) <= tol, (sp, d.max(), np.percentile(d, 99))      # out-of-gamut corners clip
+    # histretch letters: as written the non-BGR letters leave the round trip; fixed order keeps the stretch
+    img = rng.integers(40, 200, (48, 64, 3), dtype=np.uint8)
+    for letters, sp in (("l", 2), ("L", 3), ("V", 1), ("Y", 4)):
+        rt = orc.cvt_space(orc.cvt_space(img, sp), sp, True)
+        assert np.array_equal(orc.histretch_ex(img, letters), rt)
+        fx = orc.histretch_ex(img, letters, fixed_order=True)
+        conv = orc.cvt_space(img, sp)
+        orc.imgChannelStretch(conv[:, :, orc.numChannel(letters)], 2, 98)
+        assert np.array_equal(fx, orc.cvt_space(conv, sp, True)) and not np.array_equal(fx, rt)
+    # the older entry point and the new one agree on the spaces both know
+    assert np.array_equal(orc.histretch(img, "RVGY")[0], orc.histretch_ex(img, "RVGY"))

@@ -73,6 +73,8 @@ SIGNATURES = {
     "uwip_apply_lut": (C.c_int, [_P, _B, _P]),
     "uwip_imgChannelStretch": (C.c_int, [_P, _B, C.c_int, C.c_int, C.c_int]),
     "uwip_histretch": (C.c_int, [_P, _B, C.c_char_p, C.c_int, C.c_int]),
+    "uwip_histretch_ex": (C.c_int, [_P, _B, C.c_char_p, C.c_int, C.c_int, C.c_uint]),
+    "uwip_cvtColor": (C.c_int, [_P, _B, _B, C.c_int, C.c_int]),
     "uwip_bgr_to_v": (C.c_int, [_P, _B, _B]),
     "uwip_clahe": (C.c_int, [_P, _B, _B, C.c_double, C.c_int, C.c_int, C.c_int]),
     "uwip_clahe_per_frame": (C.c_int, [_P, _B, _B, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int]),

@@ -454,20 +454,19 @@ __global__ __launch_bounds__(256) void k_ycrcb_roundtrip(uint8_t *__restrict__ i
 }
 }  // namespace
 
-UWIP_API int uwip_histretch(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi)
+int uwip_cvt_space_internal(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int space, int dir);   // colorspace.hip
+
+UWIP_API int uwip_histretch_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi, unsigned flags)
 {
     int rc = uwip_check_batch(ctx, img, 3);
     if (rc) return rc;
     UWIP_REQUIRE(ctx, letters != nullptr, "null letters");
-    // validate first: HLS / Lab letters are refused before anything is touched
-    for (const char *c = letters; *c; ++c) {
-        const int sp = uwip_numSpace(*c);
-        if (sp == 2 || sp == 3)
-            return ctx->fail(UWIP_ERR_UNSUPPORTED, "HLS / Lab letters of histretch are not implemented (HSV and YCrCb are)");
-    }
-    // Runs of BGR letters are composed into one LUT pass; an HSV / YCrCb letter is, as written in the reference
-    // (histretch.cpp:230-241), the colour round trip of the image: the stretch goes to a split copy and
-    // cvtColor(dst -> src) converts the unstretched planes back before the merge.
+    UWIP_REQUIRE(ctx, (flags & ~(unsigned)UWIP_HISTRETCH_FIXED_ORDER) == 0, "unknown flag");
+    const bool fixed = (flags & UWIP_HISTRETCH_FIXED_ORDER) != 0;
+    // Runs of BGR letters are composed into one LUT pass.  A letter of another colour space is, as written in the
+    // reference (histretch.cpp:230-241), the 8-bit colour round trip of the image: the stretch goes to a
+    // split copy and cvtColor(dst -> src) converts the unstretched planes back before the merge.  With
+    // UWIP_HISTRETCH_FIXED_ORDER the evident intent runs instead: convert, stretch the letter's plane, convert back.
     LetterList L{};
     L.n = 0;
     auto flush = [&]() -> int {
@@ -487,16 +486,37 @@ UWIP_API int uwip_histretch(uwip_ctx *ctx, const uwip_batch_u8 *img, const char 
         rc = flush();
         if (rc) return rc;
         if (uwip_batch_empty(img)) continue;
-        if (sp == 1) {
+        if (fixed) {
+            uwip_batch_u8 tmp = *img;
+            tmp.data = uwip_ws(ctx, "histretch.space", (size_t)img->rows * img->cols * 3 * img->frames);
+            if (!tmp.data) return UWIP_ERR_NOMEM;
+            tmp.step = (size_t)img->cols * 3; tmp.frame_stride = tmp.step * img->rows;
+            rc = uwip_cvt_space_internal(ctx, img, &tmp, sp, 0);                 // cvtColor(src, dst, BGR2xxx)   :232
+            if (rc) return rc;
+            LetterList one{};
+            one.n = 1; one.plane[0] = (int8_t)uwip_numChannel(*c);
+            rc = stretch_planes(ctx, &tmp, one, lo, hi);                         // split / imgChannelStretch / merge   :234-236,240
+            if (rc) return rc;
+            rc = uwip_cvt_space_internal(ctx, &tmp, img, sp, 1);                 // cvtColor(dst, src, xxx2BGR) AFTER the merge
+            if (rc) return rc;
+        } else if (sp == 1) {
             rc = uwip_hsv_roundtrip(ctx, img);
             if (rc) return rc;
-        } else {
+        } else if (sp == 4) {
             UWIP_REQUIRE(ctx, img->rows <= 65535 && img->frames <= 65535, "too many rows/frames for one launch");
             uwip_kscope ks(ctx, "k_ycrcb_roundtrip");
             k_ycrcb_roundtrip<<<dim3(uwip_cdiv(img->cols, 256), (unsigned)img->rows, (unsigned)img->frames), 256, 0, ctx->stream>>>(
                 (uint8_t *)img->data, img->step, img->frame_stride, img->rows, img->cols);
             UWIP_HIP(ctx, hipGetLastError());
+        } else {
+            rc = uwip_cvt_space_internal(ctx, img, img, sp, 2);                  // HLS / Lab: the 8-bit round trip
+            if (rc) return rc;
         }
     }
     return flush();
+}
+
+UWIP_API int uwip_histretch(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi)
+{
+    return uwip_histretch_ex(ctx, img, letters, lo, hi, 0u);
 }

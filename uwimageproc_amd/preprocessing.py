@@ -49,9 +49,21 @@ def imgChannelStretch(ctx: Context, imgOriginal: torch.Tensor, imgStretched: tor
     ctx.sync()
 
 
-def histretch(ctx: Context, src: torch.Tensor, cChannel: str, min_percent: int = 2, max_percent: int = 98) -> None:
-    """histretch.cpp:217-254 (CPU branch) on BGR frames, in place."""
+def histretch(ctx: Context, src: torch.Tensor, cChannel: str, min_percent: int = 2, max_percent: int = 98,
+              fixed_order: bool = False) -> None:
+    """histretch.cpp:217-254 (CPU branch) on BGR frames, in place.  fixed_order=True keeps the stretch of the
+    non-BGR letters (merge before converting back) instead of the reference's as-written round trip (B-3)."""
     b = batch_of(src)
     torch.cuda.current_stream(src.device).synchronize()
-    ctx.call("uwip_histretch", C.byref(b), cChannel.encode(), int(min_percent), int(max_percent))
+    ctx.call("uwip_histretch_ex", C.byref(b), cChannel.encode(), int(min_percent), int(max_percent), 1 if fixed_order else 0)
     ctx.sync()
+
+
+def cvtColor(ctx: Context, src: torch.Tensor, space: int, to_bgr: bool = False) -> torch.Tensor:
+    """cv::cvtColor(src, COLOR_BGR2{HSV,HLS,Lab,YCrCb}) / the inverse, 8UC3; space = numSpace's index 1..4."""
+    dst = torch.empty_like(src)
+    sb, db = batch_of(src), batch_of(dst)
+    torch.cuda.current_stream(src.device).synchronize()
+    ctx.call("uwip_cvtColor", C.byref(sb), C.byref(db), int(space), 1 if to_bgr else 0)
+    ctx.sync()
+    return dst
