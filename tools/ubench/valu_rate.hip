@@ -36,6 +36,16 @@ __global__ __launch_bounds__(256) void k(float *out, const float *in, int iters,
         if (OP == 11) { REP8(asm volatile("v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4\n v_pk_fma_f32 %0, %0, %4, %4\n v_pk_fma_f32 %1, %1, %4, %4\n v_pk_fma_f32 %2, %2, %4, %4\n v_pk_fma_f32 %3, %3, %4, %4" : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(*(double*)&b));) }
         if (OP == 12) { REP8(asm volatile("v_mad_u32_u24 %0, %0, %8, %9\n v_mad_u32_u24 %1, %1, %8, %9\n v_mad_u32_u24 %2, %2, %8, %9\n v_mad_u32_u24 %3, %3, %8, %9\n v_mad_u32_u24 %4, %4, %8, %9\n v_mad_u32_u24 %5, %5, %8, %9\n v_mad_u32_u24 %6, %6, %8, %9\n v_mad_u32_u24 %7, %7, %8, %9" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(ua), "v"(b));) }
         if (OP == 13) { REP8(asm volatile("v_cvt_f16_u16_sdwa %0, %8 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0\n v_cvt_f16_u16_sdwa %1, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\n v_cvt_f16_u16_sdwa %2, %8 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n v_cvt_f16_u16_sdwa %3, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3\n v_cvt_f16_u16_sdwa %4, %8 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0\n v_cvt_f16_u16_sdwa %5, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_1\n v_cvt_f16_u16_sdwa %6, %8 dst_sel:WORD_0 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_2\n v_cvt_f16_u16_sdwa %7, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:BYTE_3" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(ua));) }
+        if (OP == 30) { REP8(asm volatile("v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4\n v_fma_f64 %0, %0, %4, %4\n v_fma_f64 %1, %1, %4, %4\n v_fma_f64 %2, %2, %4, %4\n v_fma_f64 %3, %3, %4, %4" : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(*(double*)&b));) }
+        if (OP == 31) { REP8(asm volatile("v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4\n v_add_f64 %0, %0, %4\n v_add_f64 %1, %1, %4\n v_add_f64 %2, %2, %4\n v_add_f64 %3, %3, %4" : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(*(double*)&b));) }
+        if (OP == 32) { REP8(asm volatile("v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4\n v_mul_f64 %0, %0, %4\n v_mul_f64 %1, %1, %4\n v_mul_f64 %2, %2, %4\n v_mul_f64 %3, %3, %4" : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(*(double*)&b));) }
+        if (OP == 33) { REP8(asm volatile("v_rcp_f64 %0, %4\n v_rcp_f64 %1, %4\n v_rcp_f64 %2, %4\n v_rcp_f64 %3, %4\n v_rcp_f64 %0, %4\n v_rcp_f64 %1, %4\n v_rcp_f64 %2, %4\n v_rcp_f64 %3, %4" : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(*(double*)&b));) }
+        if (OP == 34) { REP8(asm volatile("v_cvt_f64_u32 %0, %4\n v_cvt_f64_u32 %1, %4\n v_cvt_f64_u32 %2, %4\n v_cvt_f64_u32 %3, %4\n v_cvt_f64_u32 %0, %4\n v_cvt_f64_u32 %1, %4\n v_cvt_f64_u32 %2, %4\n v_cvt_f64_u32 %3, %4" : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(ua));) }
+        if (OP == 35) { REP8(asm volatile("v_mov_b32_dpp %0, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mov_b32_dpp %1, %8 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mov_b32_dpp %2, %8 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mov_b32_dpp %3, %8 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mov_b32_dpp %4, %8 row_bcast:15 row_mask:0xa bank_mask:0xf\n v_mov_b32_dpp %5, %8 row_bcast:31 row_mask:0xc bank_mask:0xf\n v_mov_b32_dpp %6, %8 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_mov_b32_dpp %7, %8 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(ua));) }
+        if (OP == 36) { REP8(asm volatile("v_add_u32 %0, %0, %8\n v_add_u32 %1, %1, %8\n v_add_u32 %2, %2, %8\n v_add_u32 %3, %3, %8\n v_add_u32 %4, %4, %8\n v_add_u32 %5, %5, %8\n v_add_u32 %6, %6, %8\n v_add_u32 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(ua));) }
+        if (OP == 37) { REP8(asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(ua));) }
+        if (OP == 38) { REP8(asm volatile("v_mul_u32_u24 %0, %0, %8\n v_mul_u32_u24 %1, %1, %8\n v_mul_u32_u24 %2, %2, %8\n v_mul_u32_u24 %3, %3, %8\n v_mul_u32_u24 %4, %4, %8\n v_mul_u32_u24 %5, %5, %8\n v_mul_u32_u24 %6, %6, %8\n v_mul_u32_u24 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(ua));) }
+        if (OP == 39) { REP8(asm volatile("v_add_u32_dpp %0, %8, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %1, %8, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %2, %8, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %3, %8, %3 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %4, %8, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %5, %8, %5 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %6, %8, %6 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %7, %8, %7 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(ua));) }
         // LDS: 20 ds_read_b32, 23 ds_read_b64, 24 ds_read_b128, 21/22/25 ds_add_u32 (same word / same bank / linear)
         if (OP == 20) { REP8(asm volatile("ds_read_b32 %0, %8\n ds_read_b32 %1, %8 offset:256\n ds_read_b32 %2, %8 offset:512\n ds_read_b32 %3, %8 offset:768\n ds_read_b32 %4, %8 offset:1024\n ds_read_b32 %5, %8 offset:1280\n ds_read_b32 %6, %8 offset:1536\n ds_read_b32 %7, %8 offset:1792\n s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(addr));) }
         if (OP == 23) { REP8(asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:2048\n ds_read_b64 %2, %4 offset:4096\n ds_read_b64 %3, %4 offset:6144\n ds_read_b64 %0, %4 offset:8192\n ds_read_b64 %1, %4 offset:10240\n ds_read_b64 %2, %4 offset:12288\n ds_read_b64 %3, %4 offset:14336\n s_waitcnt lgkmcnt(0)" : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(addr * 2));) }
@@ -75,6 +85,12 @@ void run(const char *name, int waves_per_simd)
 
 int main()
 {
+    for (int w : {1, 2}) {
+        run<30>("v_fma_f64", w); run<31>("v_add_f64", w); run<32>("v_mul_f64", w); run<33>("v_rcp_f64", w); run<34>("v_cvt_f64_u32", w);
+        run<35>("v_mov_b32_dpp", w); run<39>("v_add_u32_dpp", w); run<36>("v_add_u32", w); run<37>("v_mov_b32", w); run<38>("v_mul_u32_u24", w);
+        printf("\n");
+    }
+    if (getenv("UB_ALL"))
     for (int w : {1, 2, 4, 8}) {
         run<0>("v_fma_f32", w); run<1>("v_mul_f32", w); run<9>("v_add_f32", w); run<2>("v_pk_mul_f32", w); run<3>("v_pk_add_f32", w);
         run<11>("v_pk_fma_f32", w); run<4>("v_cvt_f32_ubyteN", w); run<5>("v_fma_mix_f32", w); run<6>("v_cvt_pk_u8_f32", w);

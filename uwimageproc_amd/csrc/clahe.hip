@@ -379,6 +379,16 @@ constexpr int SWEEP_REP = 3;
 constexpr int SWEEP_HROWS = (SWEEP_GROUP + 1) / 2;   // two clip limits share a word: 16-bit counters (a block sees < 65536 pixels)
 constexpr int SWEEP_SPREAD = 8;    // multiple of SWEEP_THREADS / 64
 constexpr int SWEEP_RSTRIDE = SWEEP_HROWS * 256 + 8;   // +8 words: equal bins of different replicas fall in different LDS banks
+// (TL*xa1 + TR*xa)*ya1 + (BL*xa1 + BR*xa)*ya -> RNE, clamped byte; pk = TL | TR << 8 | BL << 16 | BR << 24.
+// Plain f32 multiplies and adds in OpenCV's order (no FMA): on gfx950 a v_pk_mul/add_f32 costs 2.6x a v_mul/add_f32
+// (tools/ubench/valu_rate.hip: 2.97 vs 1.14 ns per wave-instruction), so the two-rows-per-packed-pair form lost.
+__device__ __forceinline__ uint32_t sweep_eval(uint32_t pk, float xa1, float xa, float ya1, float ya)
+{
+    const float top = (float)(pk & 255u) * xa1 + (float)((pk >> 8) & 255u) * xa;
+    const float bot = (float)((pk >> 16) & 255u) * xa1 + (float)(pk >> 24) * xa;
+    return __builtin_amdgcn_cvt_pk_u8_f32(top * ya1 + bot * ya, 0, 0u);     // RNE + clamp
+}
+
 __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__restrict__ src, size_t step,
                                                      size_t fstride, int gx, int gy, float inv_tw,
                                                      float inv_th,
@@ -477,7 +487,6 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
             const float xa = txf - floorf(txf), xa1 = 1.0f - xa;
             const float tyf = (float)y * inv_th - 0.5f;
             const float ya = tyf - floorf(tyf), ya1 = 1.0f - ya;
-            const f32x2 xa1v = {xa1, xa1}, xav = {xa, xa}, yv = {ya1, ya};
             if (diffmask == (1u << SWEEP_GROUP) - 1u) {
                 // every clip limit has its own LUTs (the common case): no branches, so the 17 LUT reads go out
                 // together and their evaluations interleave
@@ -485,24 +494,15 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
 #pragma unroll
                 for (int c = 0; c < SWEEP_GROUP; ++c) pk[c] = s_pack[c * 256 + v];
 #pragma unroll
-                for (int c = 0; c < SWEEP_GROUP; ++c) {
-                    const f32x2 ac = {(float)(pk[c] & 255u), (float)((pk[c] >> 16) & 255u)};
-                    const f32x2 bd = {(float)((pk[c] >> 8) & 255u), (float)(pk[c] >> 24)};
-                    const f32x2 t = (ac * xa1v + bd * xav) * yv;
-                    atomicAdd(&my_hist[(c >> 1) * 256 + __builtin_amdgcn_cvt_pk_u8_f32(t.x + t.y, 0, 0u)], (c & 1) ? 65536u : 1u);
-                }
+                for (int c = 0; c < SWEEP_GROUP; ++c)
+                    atomicAdd(&my_hist[(c >> 1) * 256 + sweep_eval(pk[c], xa1, xa, ya1, ya)], (c & 1) ? 65536u : 1u);
                 continue;
             }
             uint32_t o = 0;
 #pragma unroll
             for (int c = 0; c < SWEEP_GROUP; ++c) {
                 if (diffmask & (1u << c)) {          // wave-uniform
-                    const uint32_t pk = s_pack[c * 256 + v];
-                    // (TL*xa1 + TR*xa)*ya1 + (BL*xa1 + BR*xa)*ya, two rows per packed-f32 pair (same op order, no FMA)
-                    const f32x2 ac = {(float)(pk & 255u), (float)((pk >> 16) & 255u)};
-                    const f32x2 bd = {(float)((pk >> 8) & 255u), (float)(pk >> 24)};
-                    const f32x2 t = (ac * xa1v + bd * xav) * yv;
-                    o = __builtin_amdgcn_cvt_pk_u8_f32(t.x + t.y, 0, 0u);     // RNE + clamp
+                    o = sweep_eval(s_pack[c * 256 + v], xa1, xa, ya1, ya);
                 } else if (single) {
                     continue;                        // one cell per block: the repeated histogram is copied at flush time
                 }
