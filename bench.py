@@ -206,7 +206,7 @@ def stage_of(kernel):
 def pmc_entry(kernel, rows, cols):
     """Committed counter digest of the same command (tools/pmc_digest.py over separate rocprofv3 --pmc passes; the
     counters cannot be read inside this process).  None when no matching profile is committed."""
-    for name in ("r02_pmc.json", "pmc_traffic.json"):
+    for name in ("r02_pmc.json",):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             e = d.get(f"{cols}x{rows}", {}).get(kernel)

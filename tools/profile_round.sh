@@ -1,15 +1,23 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): tools/profile_round.sh <tag>
-# 1. the default bench line  2. rocprofv3 kernel stats of a 64-frame single-stream run  3./4. FETCH_SIZE / WRITE_SIZE passes
-# Outputs under gpurun_out/; digest locally with
-#   python tools/prof_summary.py gpurun_out/prof_<tag> --fetch gpurun_out/pmcf_<tag> --write gpurun_out/pmcw_<tag> \
-#          --out profiles/<tag>_fullpipe_1080p_f64 --frames 64 --size 1920x1080
+#   1. the default bench line and the 4K bench line (with the paced 4K@60 stream)
+#   2. rocprofv3 --kernel-trace --stats of a single-stream 64-frame run of the SAME pipe (the command bench.py's
+#      per-kernel numbers come from: one sub-batch on one stream)
+#   3. four separate --pmc passes of that command (SQ instruction / LDS counters, FETCH_SIZE, WRITE_SIZE)
+# Outputs under gpurun_out/; digest locally with  python tools/pmc_digest.py <tag>
 set -e
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-echo "bench (default)"; timeout -k 10 500 python3 bench.py > gpurun_out/bench_${tag}.log 2>&1; tail -1 gpurun_out/bench_${tag}.log | cut -c1-400
-B="python3 bench.py --steps 3 --warmup 1 --streams 1 --frames 64 --no-cpu-baseline"
+echo "bench (default)"; timeout -k 10 500 python3 bench.py > gpurun_out/bench_${tag}.json 2> gpurun_out/bench_${tag}.err
+echo "bench (4k-paced)"; timeout -k 10 500 python3 bench.py --config 4k-paced --no-cpu-baseline --no-matcher-bench > gpurun_out/bench4k_${tag}.json 2> gpurun_out/bench4k_${tag}.err
+B="python3 bench.py --steps 3 --warmup 1 --streams 1 --frames 64 --no-cpu-baseline --no-host-buffers --no-matcher-bench"
 echo "kernel stats"; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${tag} --output-format csv -- $B > gpurun_out/prof_${tag}.log 2>&1
-echo "FETCH_SIZE"; timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmcf_${tag} --output-format csv -- $B > gpurun_out/pmcf_${tag}.log 2>&1
-echo "WRITE_SIZE"; timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmcw_${tag} --output-format csv -- $B > gpurun_out/pmcw_${tag}.log 2>&1
+i=0
+for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  echo "pmc pass $i: $set"
+  timeout -k 10 300 rocprofv3 --pmc $set -d gpurun_out/pmc_${tag}_$i --output-format csv -- $B > gpurun_out/pmc_${tag}_$i.log 2>&1
+done
 echo done
