@@ -673,17 +673,20 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
 typedef int v4i __attribute__((ext_vector_type(4)));
 constexpr int MT_ROW = DESC_K + 16;
 
-struct Top2 {
-    int d0, i0, d1, i1;
-};
-__device__ __forceinline__ bool lessdi(int da, int ia, int db, int ib) { return da < db || (da == db && ia < ib); }
-__device__ __forceinline__ void top2_insert(Top2 &t, int d, int i)
+// Top-2 of (distance, index) pairs under the order "smaller distance, then lower index" (BFMatcher::knnMatch k = 2 with
+// ties to the lower train index) on PACKED keys: key = distance << 11 | index (distance <= 512, index < 2048), so
+// the lexicographic order is the integer order and one candidate costs a max and two mins instead of two
+// compares and four selects per slot.  b0 <= b1 always; empty slots hold MT_EMPTY.
+constexpr uint32_t MT_EMPTY = 0xffffffffu;
+__device__ __forceinline__ void top2_push(uint32_t &b0, uint32_t &b1, uint32_t k)
 {
-    if (lessdi(d, i, t.d0, t.i0)) { t.d1 = t.d0; t.i1 = t.i0; t.d0 = d; t.i0 = i; }
-    else if (lessdi(d, i, t.d1, t.i1)) { t.d1 = d; t.i1 = i; }
+    b1 = min(b1, max(b0, k));     // the second smallest of three (b0 <= b1)
+    b0 = min(b0, k);
 }
 
-__global__ __launch_bounds__(256) void k_ov_match(const int8_t *__restrict__ qbits, const int32_t *__restrict__ qpop,
+// QT query tiles of 16 per wave: every train fragment read from LDS feeds QT MFMAs
+template <int QT, int NW>
+__global__ __launch_bounds__(64 * NW) void k_ov_match(const int8_t *__restrict__ qbits, const int32_t *__restrict__ qpop,
                                                  const int32_t *__restrict__ qn, const int8_t *__restrict__ tbits,
                                                  const int32_t *__restrict__ tpop, const int32_t *__restrict__ tn,
                                                  const int32_t *__restrict__ pair_q, const int32_t *__restrict__ pair_t,
@@ -693,69 +696,91 @@ __global__ __launch_bounds__(256) void k_ov_match(const int8_t *__restrict__ qbi
     const int p = blockIdx.y;
     const int fq = pair_q[p], ft = pair_t[p];
     const int nq = qn[fq], nt = tn[ft];
-    const int q0 = blockIdx.x * 64;
+    const int q0 = blockIdx.x * (16 * NW * QT);
     if (q0 >= nq) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = lane & 15, kb = lane >> 4;
     const int8_t *Q = qbits + (size_t)fq * MAXKP * DESC_K;
     const int8_t *T = tbits + (size_t)ft * MAXKP * DESC_K;
-    // A fragments: query (q0 + wave*16 + row), bytes [64*ks + 16*kb, +16)
-    v4i a[8];
-    const int qrow = q0 + wave * 16 + row;
+    // A fragments: query (q0 + (wave * QT + u) * 16 + row), bytes [64*ks + 16*kb, +16)
+    v4i a[QT][8];
+    uint32_t cq11[QT][4];            // popcount of this lane's 4 accumulator rows, << 11
+    uint32_t b0[QT][4], b1[QT][4];
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-        a[ks] = *reinterpret_cast<const v4i *>(Q + (size_t)qrow * DESC_K + ks * 64 + kb * 16);
-    // this lane's 4 accumulator rows: q = q0 + wave*16 + kb*4 + r
-    int cq[4];
-    Top2 best[4];
+    for (int u = 0; u < QT; ++u) {
+        const int qrow = q0 + (wave * QT + u) * 16 + row;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        cq[r] = qpop[(size_t)fq * MAXKP + q0 + wave * 16 + kb * 4 + r];
-        best[r] = {1 << 30, 1 << 30, 1 << 30, 1 << 30};
+        for (int ks = 0; ks < 8; ++ks)
+            a[u][ks] = *reinterpret_cast<const v4i *>(Q + (size_t)qrow * DESC_K + ks * 64 + kb * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cq11[u][r] = (uint32_t)qpop[(size_t)fq * MAXKP + q0 + (wave * QT + u) * 16 + kb * 4 + r] << 11;
+            b0[u][r] = b1[u][r] = MT_EMPTY;
+        }
     }
+    // 64 train descriptors (32 KB) per tile: 2048 16-byte pieces, 8 per thread.  The NEXT tile's pieces are requested
+    // into registers before this tile's MFMAs, so the global-memory latency (it was exposed twice per tile between the
+    // barriers and held the kernel at 18 % of the matrix peak) hides behind them.
+    constexpr int NP = 2048 / (64 * NW);      // 16-byte pieces per thread
+    v4i stage[NP];
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = threadIdx.x + 64 * NW * j, tr = i >> 5, piece = i & 31;
+            stage[j] = *reinterpret_cast<const v4i *>(T + (size_t)(t0 + tr) * DESC_K + piece * 16);
+        }
+    };
+    if (nt > 0) fetch(0);
     for (int t0 = 0; t0 < nt; t0 += 64) {
-        __syncthreads();
-        // stage 64 train descriptors (32 KB): 2048 x 16-byte pieces, 8 per thread
-        for (int i = threadIdx.x; i < 64 * (DESC_K / 16); i += 256) {
-            const int tr = i >> 5, piece = i & 31;
-            const v4i v = *reinterpret_cast<const v4i *>(T + (size_t)(t0 + tr) * DESC_K + piece * 16);
-            *reinterpret_cast<v4i *>(s_t + (size_t)tr * MT_ROW + piece * 16) = v;
+        __syncthreads();                         // everyone is done with the previous tile
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = threadIdx.x + 64 * NW * j, tr = i >> 5, piece = i & 31;
+            *reinterpret_cast<v4i *>(s_t + (size_t)tr * MT_ROW + piece * 16) = stage[j];
         }
         __syncthreads();
+        if (t0 + 64 < nt) fetch(t0 + 64);        // rows up to MAXKP exist for every slot (zero descriptors past the count)
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            v4i acc = {0, 0, 0, 0};
+            v4i acc[QT];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) acc[u] = v4i{0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 const v4i b = *reinterpret_cast<const v4i *>(s_t + (size_t)(tt * 16 + row) * MT_ROW + ks * 64 + kb * 16);
-                acc = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[ks], b, acc, 0, 0, 0);
-            }
-            const int t = t0 + tt * 16 + row;           // C/D: col = lane & 15, row = (lane >> 4) * 4 + reg
-            if (t < nt) {
-                const int ct = tpop[(size_t)ft * MAXKP + t];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) top2_insert(best[r], cq[r] + ct - 2 * acc[r], t);
+                for (int u = 0; u < QT; ++u) acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[u][ks], b, acc[u], 0, 0, 0);
             }
+            // C/D: col = lane & 15 (train t), row = (lane >> 4) * 4 + reg (query).  popcount(a xor b) = |a| + |b| - 2 a.b
+            const int t = t0 + tt * 16 + row;
+            // (|b| << 11 | t) for a live column; a dead one (t >= nt) keeps every key above any live key
+            const uint32_t tbase = t < nt ? (((uint32_t)tpop[(size_t)ft * MAXKP + t] << 11) | (uint32_t)t) : 0x7ff00000u;
+#pragma unroll
+            for (int u = 0; u < QT; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    top2_push(b0[u][r], b1[u][r], (tbase + cq11[u][r]) - ((uint32_t)acc[u][r] << 12));
         }
     }
     // merge the 16 lanes (lane & 15) that hold different columns of the same query rows
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
+    for (int u = 0; u < QT; ++u)
 #pragma unroll
-        for (int d = 1; d < 16; d <<= 1) {
-            const int od0 = __shfl_xor(best[r].d0, d, 64), oi0 = __shfl_xor(best[r].i0, d, 64);
-            const int od1 = __shfl_xor(best[r].d1, d, 64), oi1 = __shfl_xor(best[r].i1, d, 64);
-            top2_insert(best[r], od0, oi0);
-            top2_insert(best[r], od1, oi1);
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const uint32_t o0 = (uint32_t)__shfl_xor((int)b0[u][r], d, 64), o1 = (uint32_t)__shfl_xor((int)b1[u][r], d, 64);
+                top2_push(b0[u][r], b1[u][r], o0);
+                top2_push(b0[u][r], b1[u][r], o1);
+            }
+            const int q = q0 + (wave * QT + u) * 16 + kb * 4 + r;
+            if (row == 0 && q < nq) {
+                const size_t o = ((size_t)p * MAXKP + q) * 2;
+                const bool h0 = b0[u][r] < 0x7ff00000u, h1 = b1[u][r] < 0x7ff00000u;
+                out_idx[o] = h0 ? (int)(b0[u][r] & 2047u) : -1; out_idx[o + 1] = h1 ? (int)(b1[u][r] & 2047u) : -1;
+                out_dist[o] = h0 ? (int)(b0[u][r] >> 11) : -1; out_dist[o + 1] = h1 ? (int)(b1[u][r] >> 11) : -1;
+            }
         }
-        const int q = q0 + wave * 16 + kb * 4 + r;
-        if (row == 0 && q < nq) {
-            const size_t o = ((size_t)p * MAXKP + q) * 2;
-            const bool h0 = best[r].i0 < (1 << 30), h1 = best[r].i1 < (1 << 30);
-            out_idx[o] = h0 ? best[r].i0 : -1; out_idx[o + 1] = h1 ? best[r].i1 : -1;
-            out_dist[o] = h0 ? best[r].d0 : -1; out_dist[o + 1] = h1 ? best[r].d1 : -1;
-        }
-    }
 }
 
 // ---- ratio test + RANSAC homography + overlapArea, one block per pair ---------------------------------------
@@ -1623,8 +1648,10 @@ UWIP_API int uwip_overlap_match(uwip_ctx *ctx, const uwip_features *fq, const uw
     {
         uwip_kscope ks(ctx, "k_ov_match");
         const size_t lds = (size_t)64 * MT_ROW;
-        k_ov_match<<<dim3(MAXKP / 64, npairs), 256, lds, ctx->stream>>>(fq->d_bits, fq->d_pop, fq->d_n, ft->d_bits, ft->d_pop, ft->d_n,
-                                                                       d_pairs, d_pairs + npairs, m_idx, m_dist);
+        constexpr int QT = 2;            // 2 tiles x 8 waves = 256 queries per block
+        constexpr int NW = 8;
+        k_ov_match<QT, NW><<<dim3(MAXKP / (16 * NW * QT), npairs), 64 * NW, lds, ctx->stream>>>(fq->d_bits, fq->d_pop, fq->d_n, ft->d_bits, ft->d_pop, ft->d_n,
+                                                                                    d_pairs, d_pairs + npairs, m_idx, m_dist);
         UWIP_HIP(ctx, hipGetLastError());
     }
     {
