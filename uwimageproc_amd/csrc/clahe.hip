@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void k_bgr_to_v(const uint8_t *__restrict__ sr
 // exact in fixed point, so the result is (sum of the 3x3 window weighted 1 2 1 / 2 4 2 / 1 2 1) / 16 rounded:
 //   rule 0 (OpenCV 3.4.x, bit-exact 8-bit path: ufixedpoint16 -> uchar adds one half and truncates): round half UP
 //   rule 1 (OpenCV 3.2, float rows/columns + cvRound): round half to EVEN.   parity unpinned (OpenCV-internal).
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_gauss3_u8(const uint8_t *__restrict__ src, size_t sstep, size_t sfs,
                                                    uint8_t *__restrict__ dst, size_t dstep, size_t dfs, int rows, int cols, int rule)
 {
@@ -132,13 +133,40 @@ __global__ __launch_bounds__(256) void k_gauss3_u8(const uint8_t *__restrict__ s
     const uint8_t *r0 = src + (size_t)f * sfs + (size_t)ym * sstep, *r1 = src + (size_t)f * sfs + (size_t)y * sstep,
                   *r2 = src + (size_t)f * sfs + (size_t)yp * sstep;
     uint8_t *d = dst + (size_t)f * dfs + (size_t)y * dstep;
+    auto finish = [&](int s) -> uint32_t {                     // s = window sum, <= 16 * 255
+        int q = (s + 8) >> 4;                                  // half up
+        if (rule == 1 && (s & 15) == 8) q = ((s >> 4) & 1) ? (s >> 4) + 1 : (s >> 4);      // tie -> even
+        return (uint32_t)q;
+    };
+    if (VEC) {
+        // four pixels per thread: the vertical 1 2 1 sums of six columns (x-1 .. x+4) from three dwords per row, as
+        // 16-bit lanes (<= 4 * 255), then the horizontal 1 2 1
+        const int n4 = cols >> 2;
+        for (int g = blockIdx.x * 256 + threadIdx.x; g < n4; g += gridDim.x * 256) {
+            const int gl = g == 0 ? 0 : g - 1, gr = g == n4 - 1 ? g : g + 1;
+            uint32_t v[6];
+            {
+                const uint32_t *p0 = reinterpret_cast<const uint32_t *>(r0), *p1 = reinterpret_cast<const uint32_t *>(r1),
+                               *p2 = reinterpret_cast<const uint32_t *>(r2);
+                const uint32_t a0 = p0[g], a1 = p1[g], a2 = p2[g], l0 = p0[gl], l1 = p1[gl], l2 = p2[gl], q0 = p0[gr], q1 = p1[gr], q2 = p2[gr];
+                auto col = [](uint32_t u0, uint32_t u1, uint32_t u2, int k) { return ((u0 >> (8 * k)) & 255u) + 2u * ((u1 >> (8 * k)) & 255u) + ((u2 >> (8 * k)) & 255u); };
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[1 + k] = col(a0, a1, a2, k);
+                // reflect-101 at the row ends: column -1 mirrors column 1, column W mirrors column W-2
+                v[0] = g == 0 ? v[2] : col(l0, l1, l2, 3);
+                v[5] = g == n4 - 1 ? v[3] : col(q0, q1, q2, 0);
+            }
+            uint32_t o = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o |= finish((int)(v[k] + 2u * v[k + 1] + v[k + 2])) << (8 * k);
+            reinterpret_cast<uint32_t *>(d)[g] = o;
+        }
+        return;
+    }
     for (int x = blockIdx.x * 256 + threadIdx.x; x < cols; x += gridDim.x * 256) {
         const int xm = cols == 1 ? 0 : (x == 0 ? 1 : x - 1), xp = cols == 1 ? 0 : (x == cols - 1 ? cols - 2 : x + 1);
         const int v0 = r0[xm] + 2 * r0[x] + r0[xp], v1 = r1[xm] + 2 * r1[x] + r1[xp], v2 = r2[xm] + 2 * r2[x] + r2[xp];
-        const int s = v0 + 2 * v1 + v2;                       // <= 16 * 255
-        int q = (s + 8) >> 4;                                  // half up
-        if (rule == 1 && (s & 15) == 8) q = ((s >> 4) & 1) ? (s >> 4) + 1 : (s >> 4);      // tie -> even
-        d[x] = (uint8_t)q;
+        d[x] = (uint8_t)finish(v0 + 2 * v1 + v2);
     }
 }
 
@@ -726,9 +754,14 @@ UWIP_API int uwip_GaussianBlur3(uwip_ctx *ctx, const uwip_batch_u8 *src, const u
     UWIP_REQUIRE(ctx, src->data != dst->data, "GaussianBlur3 cannot run in place");
     UWIP_REQUIRE(ctx, src->frames <= 65535 && src->rows <= 65535, "batch too large for one launch");
     uwip_kscope ks(ctx, "k_gauss3_u8");
-    const dim3 grid(std::min(uwip_cdiv(src->cols, 256), 64u), (unsigned)src->rows, (unsigned)src->frames);
-    k_gauss3_u8<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, (uint8_t *)dst->data, dst->step,
-                                              dst->frame_stride, src->rows, src->cols, rounding_rule);
+    const bool vec = src->cols >= 8 && src->cols % 4 == 0 && aligned_for(src, 4) && aligned_for(dst, 4);
+    const dim3 grid(std::min(uwip_cdiv(vec ? src->cols / 4 : src->cols, 256), 64u), (unsigned)src->rows, (unsigned)src->frames);
+    if (vec)
+        k_gauss3_u8<true><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, (uint8_t *)dst->data, dst->step,
+                                                        dst->frame_stride, src->rows, src->cols, rounding_rule);
+    else
+        k_gauss3_u8<false><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, (uint8_t *)dst->data, dst->step,
+                                                         dst->frame_stride, src->rows, src->cols, rounding_rule);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
