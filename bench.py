@@ -323,10 +323,12 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
     dom["share_of_step"] = kernels[dom_name]["ms_per_step"] / tot
     e = pmc_entry(dom_name, H, W)
     if e is not None and e.get("valu_insts_per_frame"):
-        ginstr = e["valu_insts_per_frame"] * (Fs * nprof / dcnt) / ((dms / dcnt) * 1e-3) / 1e9
-        dom["valu"] = {"wave_instr_per_launch": e["valu_insts_per_frame"] * (Fs * nprof / dcnt), "achieved_Ginstr_per_s": ginstr,
+        ginstr = e["valu_insts_per_frame"] * Fs / ((dms / dcnt) * 1e-3) / 1e9          # every launch covers the whole sub-batch
+        dom["valu"] = {"wave_instr_per_launch": e["valu_insts_per_frame"] * Fs, "achieved_Ginstr_per_s": ginstr,
                        "peak_Ginstr_per_s": VALU_PEAK_GINSTR, "frac": ginstr / VALU_PEAK_GINSTR,
-                       "source": "SQ_INSTS_VALU of the committed rocprofv3 --pmc pass (profiles/), time from this run"}
+                       "source": "SQ_INSTS_VALU of the committed rocprofv3 --pmc pass (profiles/), time from this run; the peak assumes "
+                                 "one wave64 instruction per 4 clocks per SIMD at 2.4 GHz (measured: v_mul/add_f32 issue in 1.14 ns, "
+                                 "v_cvt / v_perm / address ops in 1.83 ns, v_pk_*_f32 in 2.97 ns: tools/ubench/valu_rate.hip)"}
     roof["dominant"] = dom
     # (3) per stage: kernel time against the stage's 8(d) algorithmic bytes
     stages = {}

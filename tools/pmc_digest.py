@@ -31,8 +31,12 @@ def main():
     g = os.path.join(ROOT, "gpurun_out")
     out = os.path.join(ROOT, "profiles")
     # kernel stats
+    def newest(pattern):          # a directory may hold the CSVs of an earlier run of the same tag: digest the latest only
+        fs = glob.glob(pattern, recursive=True)
+        return [max(fs, key=os.path.getmtime)] if fs else []
+
     rows = collections.OrderedDict()
-    for f in glob.glob(os.path.join(g, f"prof_{a.tag}", "**", "*kernel_stats.csv"), recursive=True):
+    for f in newest(os.path.join(g, f"prof_{a.tag}", "**", "*kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
             k = short(r["Name"])
             e = rows.setdefault(k, [0, 0.0])
@@ -45,7 +49,11 @@ def main():
             w.writerow([k, c, f"{t/1e6:.3f}", f"{t/c/1e3:.2f}", f"{100*t/tot:.2f}"])
     # counters: average per launch, per kernel
     agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
-    for f in glob.glob(os.path.join(g, f"pmc_{a.tag}_*", "**", "*counter_collection.csv"), recursive=True):
+    pmc_files = []
+    for d in glob.glob(os.path.join(g, f"pmc_{a.tag}_*")):
+        if os.path.isdir(d):
+            pmc_files += newest(os.path.join(d, "**", "*counter_collection.csv"))
+    for f in pmc_files:
         for r in csv.DictReader(open(f)):
             c = agg[short(r["Kernel_Name"])][r["Counter_Name"]]
             c[0] += float(r["Counter_Value"]); c[1] += 1
