@@ -559,6 +559,8 @@ def main():
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist
+        sys.stdout.flush()
+        dist.barrier()                      # rank 0 may still have been printing its per-kernel report
         dist.destroy_process_group()
 
 
