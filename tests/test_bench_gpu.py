@@ -33,3 +33,19 @@ def test_bench_self_launches_two_ranks():
     assert abs(f1 - 8) < 1e-6 and abs(f2 - 16) < 1e-6
     assert one["host_buffers"] is not None and one["host_buffers"]["downloaded_equals_device"]
     assert one["roofline"] is not None and "dominant" in one["roofline"]
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's N > 1 form: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` (here two gloo ranks
+    sharing the one GPU of the test box)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["UWIP_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "8",
+           "--streams", "2", "--rows", "270", "--cols", "480", "--no-cpu-baseline", "--no-matcher-bench"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and abs(d["value"] * d["ms_per_step"] / 1e3 - 16) < 1e-6 and d["scaling"] == "weak"
