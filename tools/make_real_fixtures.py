@@ -16,7 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/modules/bgdehaze"
 OUT = os.path.join(ROOT, "tests", "golden", "real")
 
-FILES = [("img/BUL_T1A_0028.jpg", "in_BUL_T1A_0028.jpg"), ("img/BUL_T1A_0209.jpg", "in_BUL_T1A_0209.jpg"),
+FILES = [("../aclahe/python/crowd.png", "in_aclahe_crowd.png"),      # the image modules/aclahe/python/main.py reads (800x600, 8-bit grey)
+         ("img/BUL_T1A_0028.jpg", "in_BUL_T1A_0028.jpg"), ("img/BUL_T1A_0209.jpg", "in_BUL_T1A_0209.jpg"),
          ("img/PIS_T1A_259.jpg", "in_PIS_T1A_259.jpg"), ("result/BUL_T1A_0209.jpg", "ref_result_BUL_T1A_0209.jpg")]
 
 
@@ -26,13 +27,27 @@ def main():
     for src, dst in FILES:
         shutil.copyfile(os.path.join(REF, src), os.path.join(OUT, dst))
         os.chmod(os.path.join(OUT, dst), 0o644)
-        man[dst] = {"from": "modules/bgdehaze/" + src, "sha256": hashlib.sha256(open(os.path.join(OUT, dst), "rb").read()).hexdigest()}
+        man[dst] = {"from": os.path.normpath("modules/bgdehaze/" + src), "sha256": hashlib.sha256(open(os.path.join(OUT, dst), "rb").read()).hexdigest()}
     json.dump(man, open(os.path.join(OUT, "MANIFEST.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(man, indent=1))
 
 
 if __name__ == "__main__":
     main()
+
+
+def crops():
+    """The reference also ships two LOSSLESS outputs: result/restoredFiltered.png = main.py on img/BUL_T1A_0028.jpg and
+    result/restoredFiltered2.png = main.py on img/PIS_T1A_259.jpg (identified by content: tests/test_real_images.py).
+    They are 3.7 + 1.6 MB; the central 960 x 540 window of each is kept (PNG, lossless) -- a quarter of the pixels is
+    plenty for per-pixel agreement statistics."""
+    from PIL import Image
+    y0, y1, x0, x1 = 270, 810, 480, 1440
+    for src, dst in (("result/restoredFiltered.png", "ref_result_BUL_T1A_0028_crop.png"), ("result/restoredFiltered2.png", "ref_result_PIS_T1A_259_crop.png")):
+        im = Image.open(os.path.join(REF, src)).convert("RGB").crop((x0, y0, x1, y1))
+        im.save(os.path.join(OUT, dst), optimize=True)
+    json.dump({"window_rows": [y0, y1], "window_cols": [x0, x1], "files": {"ref_result_BUL_T1A_0028_crop.png": "in_BUL_T1A_0028.jpg",
+               "ref_result_PIS_T1A_259_crop.png": "in_PIS_T1A_259.jpg"}}, open(os.path.join(OUT, "crops.json"), "w"), indent=1, sort_keys=True)
 
 
 def b9_indices():
@@ -61,4 +76,5 @@ def b9_indices():
 
 
 if __name__ == "__main__":
+    crops()
     b9_indices()
