@@ -293,7 +293,7 @@ struct ApplyFrame {
     const int4 *strips;     // this frame's strip list
     const uint8_t *packed;  // its packed LUT rows [(gy+1)][(gx+1)][256] uint32
     int fr;                 // frame index in src / dst
-    int nstrips, gx, TX;
+    int nstrips, gx, TX, xs;    // xs: column parts per strip
     float inv_tw, inv_th;
 };
 template <bool VEC>
@@ -303,31 +303,42 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
                                                      int gy, float inv_tw, float inv_th,
                                                      const uint8_t *__restrict__ luts,
                                                      size_t lut_fs, const int4 *__restrict__ strips,
-                                                     const int *__restrict__ frame_map, int TX,
+                                                     const int *__restrict__ frame_map, int TX, int xs,
                                                      const ApplyFrame *__restrict__ desc)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_pack[];   // [(gx+1)][256]
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_pack[];   // [cells of this block's columns][256]
     const int tid = threadIdx.x;
     const int f = blockIdx.y;
     int fr = frame_map ? frame_map[f] : f;
     const uint8_t *lbase = luts + (size_t)f * lut_fs;
+    int nstrips = (int)gridDim.x / max(xs, 1);
     if (desc) {                                     // block-uniform
         const ApplyFrame d = desc[f];
-        if ((int)blockIdx.x >= d.nstrips) return;
-        strips = d.strips; lbase = d.packed; fr = d.fr; gx = d.gx; TX = d.TX; inv_tw = d.inv_tw; inv_th = d.inv_th;
+        strips = d.strips; lbase = d.packed; fr = d.fr; gx = d.gx; TX = d.TX; xs = d.xs; inv_tw = d.inv_tw; inv_th = d.inv_th;
+        nstrips = d.nstrips;
     }
-    const int4 sd = strips[blockIdx.x];
+    // A block = one strip of rows that share (ty1, ty2) x one of xs column parts: the LUT row it stages (1 KB per
+    // interpolation cell) shrinks with the part, and tall strips amortise it over more rows (at 32 x 32 tiles and 16-row
+    // strips the LUT row was as many bytes as the pixels).
+    const int strip = (int)blockIdx.x / xs, part = (int)blockIdx.x - strip * xs;
+    if (strip >= nstrips) return;
+    const int4 sd = strips[strip];
     const int cy = sd.x, r0 = sd.y, r1 = sd.z;
+    const int groups = (cols + 7) / 8;
+    const int g_lo = (int)(((long long)groups * part) / xs), g_hi = (int)(((long long)groups * (part + 1)) / xs);
+    if (g_lo >= g_hi) return;
+    // cells touched by columns [8 g_lo, 8 g_hi): cell(x) = floor(x * inv_tw - 0.5) + 1, non-decreasing in x
+    const int c_lo = (int)floorf((float)(g_lo * 8) * inv_tw - 0.5f) + 1;
+    const int c_hi = (int)floorf((float)(min(g_hi * 8, cols) - 1) * inv_tw - 0.5f) + 1;
     // the packed LUT row of this strip's cell row: (gx+1)*256 uint32, pre-packed by k_clahe_pack
-    const uint4 *P4 = reinterpret_cast<const uint4 *>(lbase + (size_t)cy * (gx + 1) * 1024);
-    for (int idx = tid; idx < (gx + 1) * 64; idx += 256) reinterpret_cast<uint4 *>(s_pack)[idx] = P4[idx];
+    const uint4 *P4 = reinterpret_cast<const uint4 *>(lbase + ((size_t)cy * (gx + 1) + c_lo) * 1024);
+    for (int idx = tid; idx < (c_hi - c_lo + 1) * 64; idx += 256) reinterpret_cast<uint4 *>(s_pack)[idx] = P4[idx];
     (void)gy;
     __syncthreads();
     const uint8_t *sb = src + (size_t)fr * sfs;
     uint8_t *db = dst + (size_t)fr * dfs;
     const int tx = tid % TX, ty = tid / TX, TY = 256 / TX;
-    const int groups = (cols + 7) / 8;
-    for (int g = tx; g < groups; g += TX) {
+    for (int g = g_lo + tx; g < g_hi; g += TX) {
         const int x0 = g * 8;
         uint32_t base[8];
         float xa[8], xa1[8];
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
             const float fl = floorf(txf);
             xa[i] = txf - fl;
             xa1[i] = 1.0f - xa[i];
-            base[i] = (uint32_t)(((int)fl + 1) << 8);
+            base[i] = (uint32_t)(((int)fl + 1 - c_lo) << 8);
         }
         const bool full = VEC && (x0 + 8 <= cols);
         constexpr int RU = 4;                       // rows in flight per thread (memory-level parallelism)
@@ -633,12 +644,22 @@ int build_strips(uwip_ctx *ctx, const ClaheGeom &g, int max_rows, const int4 **d
     return UWIP_OK;
 }
 
-int apply_tx(const ClaheGeom &g)
+// launch shape of the interpolation for one geometry: column parts per strip, threads along x, rows per strip and the
+// cells (KB of LDS) a block can touch
+struct ApplyShape { int xs, TX, max_rows, lds_cells; };
+ApplyShape apply_shape(const ClaheGeom &g)
 {
+    ApplyShape a;
     const int groups = (g.cols + 7) / 8;
-    int TX = 256;
-    while (TX > 32 && TX / 2 >= groups) TX /= 2;
-    return TX;
+    a.xs = groups >= 128 ? 4 : (groups >= 32 ? 2 : 1);
+    const int pg = (groups + a.xs - 1) / a.xs;          // groups per part
+    a.TX = 256;
+    while (a.TX > 32 && a.TX / 2 >= pg) a.TX /= 2;
+    // strips as tall as a cell row (capped): the staged LUT bytes per pixel fall with the strip height
+    a.max_rows = std::min(std::max(g.th, 16), 64);
+    // a part of pg groups spans at most (8 pg) / tw + 2 cells
+    a.lds_cells = std::min(g.gx + 1, (8 * pg + g.tw - 1) / g.tw + 2);
+    return a;
 }
 
 // pack the LUTs of `nf` frames of one geometry into d_packed ([nf][(gy+1)][(gx+1)][256] uint32)
@@ -653,16 +674,15 @@ int launch_pack(uwip_ctx *ctx, const ClaheGeom &g, const uint8_t *d_luts, size_t
 int launch_apply(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, const ClaheGeom &g,
                  const uint8_t *d_luts, size_t lut_fs, const int *d_frame_map, int nf)
 {
+    const ApplyShape sh = apply_shape(g);
     const int4 *d_strips = nullptr;
     int nstrips = 0;
-    const int max_rows = 16;
-    int rc = build_strips(ctx, g, max_rows, &d_strips, &nstrips);
+    int rc = build_strips(ctx, g, sh.max_rows, &d_strips, &nstrips);
     if (rc) return rc;
     if (nstrips == 0) return UWIP_OK;
-    const int TX = apply_tx(g);
-    const size_t lds = (size_t)(g.gx + 1) * 256 * sizeof(uint32_t);
+    const size_t lds = (size_t)sh.lds_cells * 256 * sizeof(uint32_t);
     const bool vec = aligned_for(src, 8) && aligned_for(dst, 8);
-    dim3 grid((unsigned)nstrips, (unsigned)nf);
+    dim3 grid((unsigned)(nstrips * sh.xs), (unsigned)nf);
     const size_t pack_fs = (size_t)(g.gy + 1) * (g.gx + 1) * 1024;      // bytes per frame
     uint32_t *d_packed = (uint32_t *)uwip_ws(ctx, "clahe.packed", pack_fs * nf);
     if (!d_packed) return UWIP_ERR_NOMEM;
@@ -675,33 +695,33 @@ int launch_apply(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *d
         k_clahe_apply<true><<<grid, 256, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
                                                              (uint8_t *)dst->data, dst->step, dst->frame_stride, g.cols,
                                                              g.gx, g.gy, g.inv_tw, g.inv_th, d_luts, lut_fs, d_strips,
-                                                             d_frame_map, TX, nullptr);
+                                                             d_frame_map, sh.TX, sh.xs, nullptr);
     else
         k_clahe_apply<false><<<grid, 256, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
                                                               (uint8_t *)dst->data, dst->step, dst->frame_stride, g.cols,
                                                               g.gx, g.gy, g.inv_tw, g.inv_th, d_luts, lut_fs, d_strips,
-                                                              d_frame_map, TX, nullptr);
+                                                              d_frame_map, sh.TX, sh.xs, nullptr);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
 
 // all frames of a batch in ONE launch, each with its own geometry (desc[f], device memory)
 int launch_apply_mixed(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, const ApplyFrame *d_desc, int nf,
-                       int max_strips, int max_gx)
+                       int max_blocks, int max_cells)
 {
-    if (max_strips == 0 || nf == 0) return UWIP_OK;
-    const size_t lds = (size_t)(max_gx + 1) * 256 * sizeof(uint32_t);
+    if (max_blocks == 0 || nf == 0) return UWIP_OK;
+    const size_t lds = (size_t)max_cells * 256 * sizeof(uint32_t);
     const bool vec = aligned_for(src, 8) && aligned_for(dst, 8);
-    dim3 grid((unsigned)max_strips, (unsigned)nf);
+    dim3 grid((unsigned)max_blocks, (unsigned)nf);
     uwip_kscope ks(ctx, "k_clahe_apply");
     if (vec)
         k_clahe_apply<true><<<grid, 256, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
                                                              (uint8_t *)dst->data, dst->step, dst->frame_stride, src->cols, 0, 0,
-                                                             0.f, 0.f, nullptr, 0, nullptr, nullptr, 0, d_desc);
+                                                             0.f, 0.f, nullptr, 0, nullptr, nullptr, 0, 1, d_desc);
     else
         k_clahe_apply<false><<<grid, 256, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
                                                               (uint8_t *)dst->data, dst->step, dst->frame_stride, src->cols, 0, 0,
-                                                              0.f, 0.f, nullptr, 0, nullptr, nullptr, 0, d_desc);
+                                                              0.f, 0.f, nullptr, 0, nullptr, nullptr, 0, 1, d_desc);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
@@ -845,7 +865,7 @@ UWIP_API int uwip_clahe_per_frame(uwip_ctx *ctx, const uwip_batch_u8 *src, const
     // per group of equal grid size: tile histograms, LUTs, packed LUT rows (small launches); the interpolation itself
     // then runs ONCE over all frames with a per-frame descriptor (a launch per group would be too short to reach the
     // HBM rate: at 4K 16 frames split three ways ran at 29 % of peak, the single launch at 41 %)
-    int i = 0, max_strips = 0, max_gx = 0;
+    int i = 0, max_blocks = 0, max_cells = 0;
     size_t poff = 0;
     while (i < F) {
         int j = i;
@@ -864,23 +884,23 @@ UWIP_API int uwip_clahe_per_frame(uwip_ctx *ctx, const uwip_batch_u8 *src, const
         const size_t pack_fs = (size_t)(g.gy + 1) * (g.gx + 1) * 1024;
         rc = launch_pack(ctx, g, d_luts, (size_t)tiles * 256, nf, (uint32_t *)(d_packed + poff));
         if (rc) return rc;
+        const ApplyShape sh = apply_shape(g);
         const int4 *d_strips = nullptr;
         int nstrips = 0;
-        rc = build_strips(ctx, g, 16, &d_strips, &nstrips);
+        rc = build_strips(ctx, g, sh.max_rows, &d_strips, &nstrips);
         if (rc) return rc;
         for (int k = 0; k < nf; ++k) {
             ApplyFrame &a = h_desc[i + k];
             a.strips = d_strips; a.packed = d_packed + poff + (size_t)k * pack_fs; a.fr = order[i + k];
-            a.nstrips = nstrips; a.gx = g.gx; a.TX = apply_tx(g); a.inv_tw = g.inv_tw; a.inv_th = g.inv_th;
+            a.nstrips = nstrips; a.gx = g.gx; a.TX = sh.TX; a.xs = sh.xs; a.inv_tw = g.inv_tw; a.inv_th = g.inv_th;
         }
-        max_strips = std::max(max_strips, nstrips);
-        max_gx = std::max(max_gx, g.gx);
+        max_blocks = std::max(max_blocks, nstrips * sh.xs);
+        max_cells = std::max(max_cells, sh.lds_cells);
         poff += pack_fs * nf;
         i = j;
     }
     UWIP_HIP(ctx, hipMemcpyAsync(d_desc, h_desc, sizeof(ApplyFrame) * (size_t)F, hipMemcpyHostToDevice, ctx->stream));
-    // (two launches -- coarse grids with 9 KB of LDS, fine grids with 33 KB -- measured slower than this one: 99 vs 88 us at 4K)
-    return launch_apply_mixed(ctx, src, dst, d_desc, F, max_strips, max_gx);
+    return launch_apply_mixed(ctx, src, dst, d_desc, F, max_blocks, max_cells);
 }
 
 UWIP_API int uwip_entropy(uwip_ctx *ctx, const uwip_batch_u8 *src, float *d_entropy)
