@@ -704,7 +704,7 @@ __global__ __launch_bounds__(64 * NW) void k_ov_match(const int8_t *__restrict__
     const int8_t *T = tbits + (size_t)ft * MAXKP * DESC_K;
     // A fragments: query (q0 + (wave * QT + u) * 16 + row), bytes [64*ks + 16*kb, +16)
     v4i a[QT][8];
-    uint32_t cq11[QT][4];            // popcount of this lane's 4 accumulator rows, << 11
+    int cq[QT][4];                   // popcount of this lane's 4 accumulator rows
     uint32_t b0[QT][4], b1[QT][4];
 #pragma unroll
     for (int u = 0; u < QT; ++u) {
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(64 * NW) void k_ov_match(const int8_t *__restrict__
             a[u][ks] = *reinterpret_cast<const v4i *>(Q + (size_t)qrow * DESC_K + ks * 64 + kb * 16);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            cq11[u][r] = (uint32_t)qpop[(size_t)fq * MAXKP + q0 + (wave * QT + u) * 16 + kb * 4 + r] << 11;
+            cq[u][r] = qpop[(size_t)fq * MAXKP + q0 + (wave * QT + u) * 16 + kb * 4 + r];
             b0[u][r] = b1[u][r] = MT_EMPTY;
         }
     }
@@ -730,16 +730,33 @@ __global__ __launch_bounds__(64 * NW) void k_ov_match(const int8_t *__restrict__
             stage[j] = *reinterpret_cast<const v4i *>(T + (size_t)(t0 + tr) * DESC_K + piece * 16);
         }
     };
-    if (nt > 0) fetch(0);
-    for (int t0 = 0; t0 < nt; t0 += 64) {
-        __syncthreads();                         // everyone is done with the previous tile
+    // two LDS tiles: while tile t is multiplied, the registers holding tile t+1 (requested a whole tile earlier) are
+    // parked in the other buffer and tile t+2 is requested -- ONE barrier per tile, no wait on global memory in the loop
+    auto park = [&](int8_t *buf) {
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             const int i = threadIdx.x + 64 * NW * j, tr = i >> 5, piece = i & 31;
-            *reinterpret_cast<v4i *>(s_t + (size_t)tr * MT_ROW + piece * 16) = stage[j];
+            *reinterpret_cast<v4i *>(buf + (size_t)tr * MT_ROW + piece * 16) = stage[j];
         }
-        __syncthreads();
-        if (t0 + 64 < nt) fetch(t0 + 64);        // rows up to MAXKP exist for every slot (zero descriptors past the count)
+    };
+    int8_t *const bufA = s_t, *const bufB = s_t + (size_t)64 * MT_ROW;
+    if (nt > 0) {
+        fetch(0);
+        park(bufA);
+        if (64 < nt) fetch(64);                  // rows up to MAXKP exist for every slot (zero descriptors past the count)
+    }
+    __syncthreads();
+    for (int t0 = 0, it = 0; t0 < nt; t0 += 64, ++it) {
+        const int8_t *cur = (it & 1) ? bufB : bufA;
+        // (|b| + 512) << 11 | t for this lane's four train columns of the tile (a dead column, t >= nt, keeps every key
+        // above any live key); requested before the MFMAs so that the popcount loads hide behind them.  The query's own
+        // popcount is the same for all candidates of a row, so it is added when the result is written, not per candidate.
+        uint32_t tb[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int t = t0 + tt * 16 + row;
+            tb[tt] = t < nt ? ((((uint32_t)tpop[(size_t)ft * MAXKP + t] + 512u) << 11) | (uint32_t)t) : 0x7ff00000u;
+        }
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             v4i acc[QT];
@@ -747,20 +764,23 @@ __global__ __launch_bounds__(64 * NW) void k_ov_match(const int8_t *__restrict__
             for (int u = 0; u < QT; ++u) acc[u] = v4i{0, 0, 0, 0};
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
-                const v4i b = *reinterpret_cast<const v4i *>(s_t + (size_t)(tt * 16 + row) * MT_ROW + ks * 64 + kb * 16);
+                const v4i b = *reinterpret_cast<const v4i *>(cur + (size_t)(tt * 16 + row) * MT_ROW + ks * 64 + kb * 16);
 #pragma unroll
                 for (int u = 0; u < QT; ++u) acc[u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[u][ks], b, acc[u], 0, 0, 0);
             }
-            // C/D: col = lane & 15 (train t), row = (lane >> 4) * 4 + reg (query).  popcount(a xor b) = |a| + |b| - 2 a.b
-            const int t = t0 + tt * 16 + row;
-            // (|b| << 11 | t) for a live column; a dead one (t >= nt) keeps every key above any live key
-            const uint32_t tbase = t < nt ? (((uint32_t)tpop[(size_t)ft * MAXKP + t] << 11) | (uint32_t)t) : 0x7ff00000u;
+            // C/D: col = lane & 15 (train t), row = (lane >> 4) * 4 + reg (query).  popcount(a xor b) = |a| + |b| - 2 a.b:
+            // key = tb - (a.b << 12), one v_mad_i32_i24
 #pragma unroll
             for (int u = 0; u < QT; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    top2_push(b0[u][r], b1[u][r], (tbase + cq11[u][r]) - ((uint32_t)acc[u][r] << 12));
+                    top2_push(b0[u][r], b1[u][r], (uint32_t)(__mul24(acc[u][r], -4096) + (int)tb[tt]));
         }
+        if (t0 + 64 < nt) {
+            park((it & 1) ? bufA : bufB);        // tile t+1: its buffer was last read in iteration t-1, before that barrier
+            if (t0 + 128 < nt) fetch(t0 + 128);
+        }
+        __syncthreads();
     }
     // merge the 16 lanes (lane & 15) that hold different columns of the same query rows
 #pragma unroll
@@ -778,7 +798,8 @@ __global__ __launch_bounds__(64 * NW) void k_ov_match(const int8_t *__restrict__
                 const size_t o = ((size_t)p * MAXKP + q) * 2;
                 const bool h0 = b0[u][r] < 0x7ff00000u, h1 = b1[u][r] < 0x7ff00000u;
                 out_idx[o] = h0 ? (int)(b0[u][r] & 2047u) : -1; out_idx[o + 1] = h1 ? (int)(b1[u][r] & 2047u) : -1;
-                out_dist[o] = h0 ? (int)(b0[u][r] >> 11) : -1; out_dist[o + 1] = h1 ? (int)(b1[u][r] >> 11) : -1;
+                out_dist[o] = h0 ? (int)(b0[u][r] >> 11) - 512 + cq[u][r] : -1;
+                out_dist[o + 1] = h1 ? (int)(b1[u][r] >> 11) - 512 + cq[u][r] : -1;
             }
         }
 }
@@ -1647,9 +1668,11 @@ UWIP_API int uwip_overlap_match(uwip_ctx *ctx, const uwip_features *fq, const uw
     UWIP_HIP(ctx, hipMemcpyAsync(d_pairs, h_pairs, sizeof(int32_t) * 2 * (size_t)npairs, hipMemcpyHostToDevice, ctx->stream));
     {
         uwip_kscope ks(ctx, "k_ov_match");
-        const size_t lds = (size_t)64 * MT_ROW;
+        const size_t lds = (size_t)2 * 64 * MT_ROW;
         constexpr int QT = 2;            // 2 tiles x 8 waves = 256 queries per block
         constexpr int NW = 8;
+        int rc_l = uwip_lds_optin(ctx, "k_ov_match", (const void *)k_ov_match<QT, NW>, lds);      // 66 KB > the 64 KB default
+        if (rc_l) return rc_l;
         k_ov_match<QT, NW><<<dim3(MAXKP / (16 * NW * QT), npairs), 64 * NW, lds, ctx->stream>>>(fq->d_bits, fq->d_pop, fq->d_n, ft->d_bits, ft->d_pop, ft->d_n,
                                                                                     d_pairs, d_pairs + npairs, m_idx, m_dist);
         UWIP_HIP(ctx, hipGetLastError());
