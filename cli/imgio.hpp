@@ -1,6 +1,6 @@
-// Minimal image I/O for the CLIs: 8-bit PNG (non-interlaced grey / RGB / RGBA, via zlib) and binary
-// PPM / PGM.  Pixels are returned BGR-interleaved, as cv::imread(CV_LOAD_IMAGE_COLOR) does
-// (modules/histretch/src/histretch.cpp:158).  JPEG is not available (no codec in the build image).
+// Minimal image I/O for the CLIs: 8-bit PNG (non-interlaced grey / RGB / RGBA, via zlib), binary PPM / PGM and
+// baseline JPEG (cli/jpeg.hpp: libjpeg's algorithms restated, no codec library in the build image).  Pixels are returned
+// BGR-interleaved, as cv::imread(CV_LOAD_IMAGE_COLOR) does (modules/histretch/src/histretch.cpp:158).
 #pragma once
 #include <zlib.h>
 #include <cctype>
@@ -10,6 +10,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include "jpeg.hpp"
 
 namespace imgio {
 
@@ -137,7 +138,8 @@ inline bool imread(const std::string &path, Image &img, bool force_color = true)
 {
     std::vector<uint8_t> buf;
     if (!read_file(path, buf)) return false;
-    return read_png(buf, img, force_color) || read_pnm(buf, img, force_color);
+    if (read_png(buf, img, force_color) || read_pnm(buf, img, force_color)) return true;
+    return jpeg::decode(buf.data(), buf.size(), img.rows, img.cols, img.channels, img.data, force_color);
 }
 
 inline void put_chunk(std::vector<uint8_t> &out, const char *type, const uint8_t *d, uint32_t len)
@@ -156,6 +158,14 @@ inline bool imwrite(const std::string &path, const Image &img)
 {
     const size_t n = (size_t)img.rows * img.cols;
     std::vector<uint8_t> out;
+    if (ends_with(path, ".jpg") || ends_with(path, ".jpeg")) {
+        if (!jpeg::encode(img.data.data(), img.rows, img.cols, img.channels, 95, out)) return false;     // cv::imwrite's default quality
+        FILE *f = std::fopen(path.c_str(), "wb");
+        if (!f) return false;
+        const bool ok = std::fwrite(out.data(), 1, out.size(), f) == out.size();
+        std::fclose(f);
+        return ok;
+    }
     if (ends_with(path, ".png")) {
         const int spp = img.channels;
         std::vector<uint8_t> raw(((size_t)img.cols * spp + 1) * img.rows);

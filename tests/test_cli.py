@@ -39,6 +39,65 @@ def test_cli_builds_and_help_runs_without_gpu(tmp_path):
     assert r.returncode != 0 and "no CPU implementation" in r.stdout
 
 
+REAL = os.path.join(ROOT, "tests", "golden", "real")
+
+
+def _write_mjpeg_avi(path, jpegs, fps, width, height):
+    """A minimal RIFF AVI with one Motion-JPEG video stream (what `ffmpeg -c:v mjpeg` writes, without the index)."""
+    import struct
+    def chunk(tag, body):
+        return tag + struct.pack("<I", len(body)) + body + (b"\0" if len(body) & 1 else b"")
+    def lst(kind, body):
+        return chunk(b"LIST", kind + body)
+    avih = struct.pack("<14I", int(1e6 / fps), 0, 0, 0x10, len(jpegs), 0, 1, 0, width, height, 0, 0, 0, 0)
+    strh = b"vids" + b"MJPG" + struct.pack("<IHHIIIIIIII", 0, 0, 0, 0, 1, int(fps), 0, len(jpegs), 0, 0xFFFFFFFF, 0) + struct.pack("<4h", 0, 0, width, height)
+    strf = struct.pack("<IiiHHIIiiII", 40, width, height, 1, 24, 0x47504A4D, width * height * 3, 0, 0, 0, 0)
+    hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
+    movi = lst(b"movi", b"".join(chunk(b"00dc", j) for j in jpegs))
+    body = b"AVI " + hdrl + movi
+    open(path, "wb").write(b"RIFF" + struct.pack("<I", len(body)) + body)
+
+
+def test_jpeg_codec_against_pillow(tmp_path):
+    """cli/jpeg.hpp (libjpeg's islow IDCT, fancy upsampling, fixed-point colour; baseline encoder with the Annex K
+    tables at cv::imwrite's quality 95): the decoder returns, bit for bit, what Pillow's libjpeg returns for the
+    reference's four JPEG files; the encoder's files decode identically in Pillow and in the decoder, and on a photograph
+    to exactly what Pillow's own encoder (quality 95, 4:2:0) gives."""
+    import io
+    _build()
+    conv = os.path.join(BIN, "imgconv")
+    out = str(tmp_path / "o.png")
+    for n in ("in_BUL_T1A_0028.jpg", "in_BUL_T1A_0209.jpg", "in_PIS_T1A_259.jpg", "ref_result_BUL_T1A_0209.jpg"):
+        r = subprocess.run([conv, os.path.join(REAL, n), out], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stdout
+        assert np.array_equal(_load_png(out), np.asarray(Image.open(os.path.join(REAL, n)).convert("RGB"))[..., ::-1]), n
+    photo = np.ascontiguousarray(np.asarray(Image.open(os.path.join(REAL, "in_BUL_T1A_0028.jpg")).convert("RGB"))[:533, :801, ::-1])
+    for name, img in (("photo", photo), ("synthetic", synth.uw_stream(0, 1, 270, 483)[0])):
+        a, j, b = str(tmp_path / "a.png"), str(tmp_path / "a.jpg"), str(tmp_path / "b.png")
+        _save_png(a, img)
+        assert subprocess.run([conv, a, j], capture_output=True, timeout=120).returncode == 0
+        via_pillow = np.asarray(Image.open(j).convert("RGB"))[..., ::-1]
+        assert subprocess.run([conv, j, b], capture_output=True, timeout=120).returncode == 0
+        assert np.array_equal(_load_png(b), via_pillow), name                      # our decoder == libjpeg on our stream
+        err = np.abs(via_pillow.astype(int) - img.astype(int))
+        assert err.mean() < 3.0, (name, err.mean())                               # quality 95
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(img[..., ::-1])).save(buf, format="JPEG", quality=95, subsampling=2)
+        theirs = np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))[..., ::-1]
+        d = np.abs(via_pillow.astype(int) - theirs.astype(int))
+        if name == "photo":
+            assert d.max() == 0                 # same coefficients as libjpeg-turbo's encoder
+        else:
+            assert (d != 0).mean() < 0.05       # libjpeg-turbo's reciprocal quantiser differs from IJG's division on noise
+    # grey: 1-component stream
+    g = np.asarray(Image.open(os.path.join(REAL, "in_aclahe_crowd.png")).convert("L"))
+    a, j = str(tmp_path / "g.png"), str(tmp_path / "g.jpg")
+    Image.fromarray(g).save(a)
+    assert subprocess.run([conv, a, j, "grey"], capture_output=True, timeout=120).returncode == 0
+    im = Image.open(j)
+    assert im.mode == "L" and np.abs(np.asarray(im).astype(int) - g.astype(int)).mean() < 2.0
+
+
 @pytest.mark.gpu
 def test_histretch_cli_config0_640x480_png(tmp_path, orc):
     """BASELINE config 0: histretch on one 640x480 PNG (here through the HIP path)."""
@@ -94,7 +153,7 @@ def test_videostrip_cli_selector_and_report(tmp_path, orc):
     lst = str(tmp_path / "frames.txt")
     open(lst, "w").write("\n".join(paths) + "\n")
     prefix = str(tmp_path / "out_")
-    r = subprocess.run([os.path.join(BIN, "videostrip"), "-k", str(k), "-p", str(p), lst, prefix], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([os.path.join(BIN, "videostrip"), "-k", str(k), "-p", str(p), "--png", lst, prefix], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     rep = open(prefix + "videostrip_report.txt").read().splitlines()
     hdr = rep.index("ID\tFrame\tFilename\tOverlap\tBlur")
@@ -133,6 +192,47 @@ def test_videostrip_cli_selector_and_report(tmp_path, orc):
     c.close()
     assert len(rows) >= 2 and os.path.exists(prefix + "0000.png") and os.path.exists(prefix + f"{len(rows)-1:04d}.png")
     assert np.array_equal(_load_png(prefix + "0000.png"), frames[0])
+    # the same stream as a Motion-JPEG .avi, key frames written as .jpg like the reference (main.cpp:294,377): the frames the
+    # tool sees are the DECODED JPEGs, so the expectation is the same loop on those
+    import io
+    jpegs, dec = [], []
+    for f in frames:
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(f[..., ::-1])).save(buf, format="JPEG", quality=92, subsampling=2)
+        jpegs.append(buf.getvalue())
+        dec.append(np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))[..., ::-1]))
+    avi = str(tmp_path / "clip.avi")
+    _write_mjpeg_avi(avi, jpegs, 25.0, 640, 480)
+    prefix2 = str(tmp_path / "avi_")
+    r = subprocess.run([os.path.join(BIN, "videostrip"), "-k", str(k), "-p", str(p), avi, prefix2], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rep = open(prefix2 + "videostrip_report.txt").read().splitlines()
+    rows2 = [l.split("\t") for l in rep[rep.index("ID\tFrame\tFilename\tOverlap\tBlur") + 1:]]
+    exp2 = [("0", "0")]
+    key, nxt, read = dec[0], 1, 1
+    while nxt < n:
+        f = dec[nxt]; nxt += 1; read += 1
+        ov, _, _ = orc.calcOverlap(key, f, 640, 480, seed=1)
+        if ov == -2.0:
+            ov = 0.41
+        if ov <= p:
+            best, bestn, bf = orc.calcBlur(f), nxt - 1, f
+            eof = False
+            for _ in range(k):
+                if nxt >= n:
+                    eof = True
+                    break
+                g = dec[nxt]; nxt += 1; read += 1
+                b = orc.calcBlur(g)
+                if b > best:
+                    best, bestn, bf = b, read, g
+            key = bf
+            exp2.append((str(len(exp2)), str(bestn)))
+            if eof:
+                break
+    assert [(r_[0], r_[1]) for r_ in rows2] == exp2, (rows2, exp2)
+    first = np.asarray(Image.open(prefix2 + "0000.jpg").convert("RGB"))[..., ::-1]
+    assert first.shape == (480, 640, 3) and np.abs(first.astype(int) - dec[0].astype(int)).mean() < 3.0
 
 
 @pytest.mark.gpu
@@ -156,3 +256,19 @@ def test_reference_signature_shims(tmp_path, orc):
     assert int(got["stretch"]) == int(st.astype(np.uint64).sum())
     assert float(got["hist0"]) == float((st[:, :, 0] == 0).sum())
     assert tok[-2:] == ["1", "1"]
+
+
+@pytest.mark.gpu
+def test_bgdehaze_cli_on_the_references_photograph(tmp_path):
+    """The reference's own use: main.py reads img/BUL_T1A_0209.jpg and writes result/BUL_T1A_0209.jpg (w = 15).  The CLI
+    does the same from the same .jpg to a .jpg; against the file the reference's authors saved: the bounds of
+    tests/test_real_images.py (first-index tie rule: mean |diff| < 7 levels, correlation > 0.99) plus one more JPEG coding."""
+    _build()
+    out = str(tmp_path / "out.jpg")
+    r = subprocess.run([os.path.join(BIN, "bgdehaze"), "-w", "15", os.path.join(REAL, "in_BUL_T1A_0209.jpg"), out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.asarray(Image.open(out).convert("RGB")).astype(int)
+    ref = np.asarray(Image.open(os.path.join(REAL, "ref_result_BUL_T1A_0209.jpg")).convert("RGB")).astype(int)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).mean() < 7.5
+    assert min(np.corrcoef(got[:, :, c].ravel(), ref[:, :, c].ravel())[0, 1] for c in range(3)) > 0.99
