@@ -6,7 +6,13 @@ import glob
 import os
 import sys
 
-from prof_summary import short
+import re
+
+
+def short(name):
+    n = name.replace("(anonymous namespace)::", "")
+    n = re.sub(r"^void ", "", n)
+    return n.split("(")[0]
 
 
 def main():
