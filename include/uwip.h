@@ -256,6 +256,14 @@ int uwip_guided_filter(uwip_ctx *ctx, const uwip_batch_u8 *guide, const double *
 int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batch_u8 *out, int w, int flags,
                 const double *d_B_inject, double *d_refined_t, double *d_float_out);
 
+/* bgdehaze -> histretch chained on one batch (BASELINE.json configs[2]; the reference runs the two tools back to back
+ * over files: modules/bgdehaze/main.py:14-20, then modules/histretch/src/histretch.cpp:218-254 on its output).  Same
+ * result as uwip_dehaze(in, out, ...) followed by uwip_histretch_ex(out, ...); with UWIP_DEHAZE_FULL the kernel
+ * that writes the dehazed bytes also counts them, so the stretch starts from a finished histogram instead of
+ * reading the image once more. */
+int uwip_dehaze_histretch(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batch_u8 *out, int w, int dehaze_flags,
+                          const char *letters, int lo, int hi, unsigned histretch_flags);
+
 /* ---- videostrip overlap (V1-V5) -------------------------------------------- */
 /* calcOverlap(keyframe*, Mat), modules/videostrip/src/videostrip.cpp:192-289, split
  * at the point where the reference caches a key frame's keypoints/descriptors in

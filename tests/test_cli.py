@@ -137,6 +137,13 @@ def test_aclahe_and_bgdehaze_cli(tmp_path, orc):
     exp = dz.to_u8(dz.RC_correction(dz.normalize_input(img), 15))
     diff = np.abs(_load_png(b).astype(int) - exp.astype(int))
     assert diff.max() <= 1 and (diff != 0).mean() <= 1e-3
+    # --histretch chains the stretch in the same run: same bytes as the two tools one after the other
+    c, d = str(tmp_path / "dz.png"), str(tmp_path / "dzhs.png")
+    for cmd in ([os.path.join(BIN, "bgdehaze"), "-w", "15", a, c], [os.path.join(BIN, "histretch"), "-c=RGB", c, d],
+                [os.path.join(BIN, "bgdehaze"), "-w", "15", "--histretch", "RGB", a, b]):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+    assert np.array_equal(_load_png(b), _load_png(d))
 
 
 @pytest.mark.gpu

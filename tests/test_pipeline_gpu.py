@@ -60,6 +60,26 @@ def test_full_pipe_small_stream(orc):
     pipe.close()
 
 
+@pytest.mark.parametrize("letters,full,fixed", [("RGB", True, False), ("B", True, False), ("RGBVR", True, False),
+                                                ("VRG", True, False), ("RlG", True, True), ("RGB", False, False),
+                                                ("", True, False), ("zz", True, False)])
+def test_chained_dehaze_histretch_equals_two_calls(letters, full, fixed):
+    """uwip_dehaze_histretch (histogram counted by the dehaze writer) == uwip_dehaze then uwip_histretch_ex, byte for
+    byte: a BGR run first (histogram reused), a colour-space letter first (it must not be), several frames and a
+    ragged width so the tail chunks of both paths are exercised."""
+    import uwimageproc_amd as uw
+    from uwimageproc_amd import bgdehaze as bg, preprocessing as pp
+    ctx = uw.Context(0)
+    frames = torch.from_numpy(synth.uw_stream(3, 3, 131, 203)).cuda()
+    two = bg.dehaze(ctx, frames, 15, full=full, guard_s=True)
+    pp.histretch(ctx, two, letters, 2, 98, fixed_order=fixed)
+    one = bg.dehaze_histretch(ctx, frames, letters, 2, 98, 15, full=full, guard_s=True, fixed_order=fixed)
+    assert torch.equal(one, two)
+    # again on the same context: the histogram workspace must be re-zeroed, not accumulated
+    again = bg.dehaze_histretch(ctx, frames, letters, 2, 98, 15, full=full, guard_s=True, fixed_order=fixed)
+    assert torch.equal(again, two)
+
+
 def test_config3_dehaze_histretch_4k(orc):
     """BASELINE config 3: bgdehaze -> histretch chained on a 3840x2160 frame.  Full-size checks through
     size-independent properties (determinism, min-max span, border transmission) plus an exact

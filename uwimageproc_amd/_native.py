@@ -91,6 +91,7 @@ SIGNATURES = {
     "uwip_dehaze_transmission": (C.c_int, [_P, _B, _P, _P]),
     "uwip_guided_filter": (C.c_int, [_P, _B, _P, C.c_int, C.c_double, _P]),
     "uwip_dehaze": (C.c_int, [_P, _B, _B, C.c_int, C.c_int, _P, _P, _P]),
+    "uwip_dehaze_histretch": (C.c_int, [_P, _B, _B, C.c_int, C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_uint]),
     "uwip_features_create": (C.c_int, [_P, C.c_int, C.POINTER(_P)]),
     "uwip_features_destroy": (C.c_int, [_P]),
     "uwip_features_copy": (C.c_int, [_P, _P, C.c_int, _P, C.c_int]),

@@ -80,6 +80,23 @@ def dehaze(ctx: Context, I: torch.Tensor, w: int = 15, full: bool = True, B: tor
     return out
 
 
+def dehaze_histretch(ctx: Context, I: torch.Tensor, cChannel: str = "RGB", min_percent: int = 2, max_percent: int = 98,
+                     w: int = 15, full: bool = True, guard_s: bool = False, fixed_order: bool = False,
+                     out: torch.Tensor = None) -> torch.Tensor:
+    """bgdehaze then histretch on its output (BASELINE configs[2]) as one chained call: the kernel that writes the
+    dehazed bytes also histograms them.  Same bytes as ``dehaze`` followed by ``preprocessing.histretch``."""
+    b = batch_of(I)
+    if out is None:
+        out = torch.empty_like(I)
+    ob = batch_of(out)
+    _pre(I)
+    flags = (DEHAZE_FULL if full else 0) | (DEHAZE_GUARD_S if guard_s else 0)
+    ctx.call("uwip_dehaze_histretch", C.byref(b), C.byref(ob), int(w), flags, cChannel.encode(), int(min_percent),
+             int(max_percent), 1 if fixed_order else 0)
+    ctx.sync()
+    return out
+
+
 def RC_correction(ctx: Context, I: torch.Tensor, w: int = 15, B: torch.Tensor = None) -> torch.Tensor:
     """BGDehaze.py:59-69 -> float64 [frames, H, W, 3]."""
     return dehaze(ctx, I, w, full=False, B=B, want_float=True)["float"]

@@ -564,15 +564,20 @@ __global__ __launch_bounds__(256) void k_exp_S(const uint8_t *__restrict__ YI, c
 }
 
 // OutputExp = restored * refinedS : PASS 0 = partial min/max, PASS 1 = normalise + write
-template <int PASS>
+// HIST (PASS 1 only): also count the bytes it writes into hist[f][channel][256] -- the histogram histretch needs of this
+// very image -- in per-wave LDS bins that drain behind the f64 stream, so the chained stage skips its own read pass.
+template <int PASS, bool HIST>
 __global__ __launch_bounds__(256) void k_exp_out(const uint8_t *__restrict__ img, size_t step, size_t fs,
                                                  const int *__restrict__ si, double *__restrict__ sc,
                                                  const double *__restrict__ Q, const double *__restrict__ RS,
                                                  int H, int W, double *__restrict__ part,
                                                  uint8_t *__restrict__ out, size_t ostep, size_t ofs,
-                                                 double *__restrict__ tap)
+                                                 double *__restrict__ tap, uint32_t *__restrict__ hist)
 {
     __shared__ double scratch[4];
+    __shared__ uint32_t s_hist[HIST ? 4 * 768 : 1];
+    uint32_t *my_hist = s_hist + (HIST ? (threadIdx.x >> 6) * 768 : 0);
+    if (HIST) for (int i = threadIdx.x; i < 4 * 768; i += 256) s_hist[i] = 0;   // fill_red_table's barrier orders this
     const int f = blockIdx.y;
     const size_t n = (size_t)H * W;
     const int mn = si[(size_t)f * SI_COUNT + SI_MN], mx = si[(size_t)f * SI_COUNT + SI_MX];
@@ -599,8 +604,18 @@ __global__ __launch_bounds__(256) void k_exp_out(const uint8_t *__restrict__ img
             if (tap) { double *t = tap + ((size_t)f * n + i) * 3; t[0] = v[0]; t[1] = v[1]; t[2] = v[2]; }
             if (out) {
                 uint8_t *o = out + (size_t)f * ofs + (size_t)y * ostep + (size_t)x * 3;
-                o[0] = f64_to_u8_rne(v[0] * 255); o[1] = f64_to_u8_rne(v[1] * 255); o[2] = f64_to_u8_rne(v[2] * 255);
+                const uint8_t b0 = f64_to_u8_rne(v[0] * 255), b1 = f64_to_u8_rne(v[1] * 255), b2 = f64_to_u8_rne(v[2] * 255);
+                o[0] = b0; o[1] = b1; o[2] = b2;
+                if (HIST) { atomicAdd(&my_hist[b0], 1u); atomicAdd(&my_hist[256 + b1], 1u); atomicAdd(&my_hist[512 + b2], 1u); }
             }
+        }
+    }
+    if (HIST) {
+        __syncthreads();
+        uint32_t *oh = hist + (size_t)f * 768;
+        for (int i = threadIdx.x; i < 768; i += 256) {
+            const uint32_t c = s_hist[i] + s_hist[768 + i] + s_hist[2 * 768 + i] + s_hist[3 * 768 + i];
+            if (c) atomicAdd(&oh[i], c);
         }
     }
     if (PASS == 0) {
@@ -816,8 +831,9 @@ UWIP_API int uwip_guided_filter(uwip_ctx *ctx, const uwip_batch_u8 *guide, const
                             d_q, b.AB, F, 1, H, W, r, eps);
 }
 
-UWIP_API int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batch_u8 *out, int w, int flags,
-                         const double *d_B_inject, double *d_refined_t, double *d_float_out)
+// d_hist_out (internal): [F][3][256] counts of the bytes written to `out`, zeroed by the caller; FULL form only
+int uwip_dehaze_internal(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batch_u8 *out, int w, int flags,
+                         const double *d_B_inject, double *d_refined_t, double *d_float_out, uint32_t *d_hist_out)
 {
     const int full = (flags & UWIP_DEHAZE_FULL) != 0, guard = (flags & UWIP_DEHAZE_GUARD_S) != 0;
     int rc = check_in(ctx, in, w);
@@ -902,12 +918,46 @@ UWIP_API int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batc
     if (rc) return rc;
     {
         uwip_kscope ks(ctx, "k_exp_out");
-        k_exp_out<0><<<dim3(RED_BLOCKS, F), 256, 0, ctx->stream>>>(img, in->step, in->frame_stride, b.si, b.sc, b.Q, RS, H, W,
-                                                                b.part, nullptr, 0, 0, nullptr);
+        k_exp_out<0, false><<<dim3(RED_BLOCKS, F), 256, 0, ctx->stream>>>(img, in->step, in->frame_stride, b.si, b.sc, b.Q, RS, H, W,
+                                                                       b.part, nullptr, 0, 0, nullptr, nullptr);
         k_exp_out_final<<<F, 64, 0, ctx->stream>>>(b.part, RED_BLOCKS, b.sc);
-        k_exp_out<1><<<dim3(512, F), 256, 0, ctx->stream>>>(img, in->step, in->frame_stride, b.si, b.sc, b.Q, RS, H, W, nullptr, o,
-                                                         ostep, ofs, d_float_out);
+        if (d_hist_out && o)
+            k_exp_out<1, true><<<dim3(512, F), 256, 0, ctx->stream>>>(img, in->step, in->frame_stride, b.si, b.sc, b.Q, RS, H, W,
+                                                                   nullptr, o, ostep, ofs, d_float_out, d_hist_out);
+        else
+            k_exp_out<1, false><<<dim3(512, F), 256, 0, ctx->stream>>>(img, in->step, in->frame_stride, b.si, b.sc, b.Q, RS, H, W,
+                                                                    nullptr, o, ostep, ofs, d_float_out, nullptr);
     }
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
+}
+
+UWIP_API int uwip_dehaze(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batch_u8 *out, int w, int flags,
+                         const double *d_B_inject, double *d_refined_t, double *d_float_out)
+{
+    return uwip_dehaze_internal(ctx, in, out, w, flags, d_B_inject, d_refined_t, d_float_out, nullptr);
+}
+
+int uwip_histretch_internal(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi, unsigned flags,
+                            bool hist_is_fresh);   // histretch.hip
+uint32_t *uwip_histretch_hist_ws(uwip_ctx *ctx, const uwip_batch_u8 *img);
+
+UWIP_API int uwip_dehaze_histretch(uwip_ctx *ctx, const uwip_batch_u8 *in, const uwip_batch_u8 *out, int w, int dehaze_flags,
+                                   const char *letters, int lo, int hi, unsigned histretch_flags)
+{
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
+    UWIP_REQUIRE(ctx, out != nullptr, "the chained form needs an output batch");
+    UWIP_REQUIRE(ctx, letters != nullptr, "null letters");
+    const bool fuse = (dehaze_flags & UWIP_DEHAZE_FULL) != 0 && in && in->frames > 0 && !uwip_batch_empty(in);
+    uint32_t *d_hist = nullptr;
+    if (fuse) {
+        int rc = uwip_check_batch(ctx, out, 3);
+        if (rc) return rc;
+        d_hist = uwip_histretch_hist_ws(ctx, out);
+        if (!d_hist) return UWIP_ERR_NOMEM;
+        UWIP_HIP(ctx, hipMemsetAsync(d_hist, 0, sizeof(uint32_t) * 768 * (size_t)out->frames, ctx->stream));
+    }
+    int rc = uwip_dehaze_internal(ctx, in, out, w, dehaze_flags, nullptr, nullptr, nullptr, d_hist);
+    if (rc) return rc;
+    return uwip_histretch_internal(ctx, out, letters, lo, hi, histretch_flags, d_hist != nullptr);
 }

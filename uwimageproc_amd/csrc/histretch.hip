@@ -339,7 +339,8 @@ int launch_apply(uwip_ctx *ctx, const uwip_batch_u8 *img, const uint8_t *d_lut)
     return UWIP_OK;
 }
 
-int stretch_planes(uwip_ctx *ctx, const uwip_batch_u8 *img, const LetterList &L, int lo, int hi)
+// have_hist: "histretch.hist" already holds this image's histogram (the dehaze writer counted it)
+int stretch_planes(uwip_ctx *ctx, const uwip_batch_u8 *img, const LetterList &L, int lo, int hi, bool have_hist = false)
 {
     if (uwip_batch_empty(img) || L.n == 0) return UWIP_OK;
     const int C = img->channels;
@@ -347,7 +348,7 @@ int stretch_planes(uwip_ctx *ctx, const uwip_batch_u8 *img, const LetterList &L,
     uint32_t *d_hist = (uint32_t *)uwip_ws(ctx, "histretch.hist", nplanes * 256 * sizeof(uint32_t));
     uint8_t *d_lut = (uint8_t *)uwip_ws(ctx, "histretch.lut", nplanes * 256);
     if (!d_hist || !d_lut) return UWIP_ERR_NOMEM;
-    int rc = launch_hist(ctx, img, d_hist);
+    int rc = have_hist ? UWIP_OK : launch_hist(ctx, img, d_hist);
     if (rc) return rc;
     {
         uwip_kscope ks(ctx, "k_compose_luts");
@@ -456,7 +457,13 @@ __global__ __launch_bounds__(256) void k_ycrcb_roundtrip(uint8_t *__restrict__ i
 
 int uwip_cvt_space_internal(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int space, int dir);   // colorspace.hip
 
-UWIP_API int uwip_histretch_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi, unsigned flags)
+uint32_t *uwip_histretch_hist_ws(uwip_ctx *ctx, const uwip_batch_u8 *img)
+{
+    return (uint32_t *)uwip_ws(ctx, "histretch.hist", (size_t)img->channels * img->frames * 256 * sizeof(uint32_t));
+}
+
+int uwip_histretch_internal(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi, unsigned flags,
+                            bool hist_is_fresh)
 {
     int rc = uwip_check_batch(ctx, img, 3);
     if (rc) return rc;
@@ -471,8 +478,9 @@ UWIP_API int uwip_histretch_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const ch
     L.n = 0;
     auto flush = [&]() -> int {
         if (L.n == 0) return UWIP_OK;
-        const int r2 = stretch_planes(ctx, img, L, lo, hi);
+        const int r2 = stretch_planes(ctx, img, L, lo, hi, hist_is_fresh);
         L.n = 0;
+        hist_is_fresh = false;
         return r2;
     };
     for (const char *c = letters; *c; ++c) {
@@ -485,6 +493,7 @@ UWIP_API int uwip_histretch_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const ch
         }
         rc = flush();
         if (rc) return rc;
+        hist_is_fresh = false;                         // the image changes below
         if (uwip_batch_empty(img)) continue;
         if (fixed) {
             uwip_batch_u8 tmp = *img;
@@ -514,6 +523,11 @@ UWIP_API int uwip_histretch_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const ch
         }
     }
     return flush();
+}
+
+UWIP_API int uwip_histretch_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi, unsigned flags)
+{
+    return uwip_histretch_internal(ctx, img, letters, lo, hi, flags, false);
 }
 
 UWIP_API int uwip_histretch(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi)

@@ -65,6 +65,12 @@ class FramePipe:
         b = batch_of(self.work)
         self.ctx.call("uwip_histretch", C.byref(b), self.letters, 2, 98)
 
+    def stage_dehaze_histretch(self, src: torch.Tensor):
+        """The two stages as one chained call: the dehaze writer hands the stretch its histogram."""
+        sb, ob = batch_of(src), batch_of(self.work)
+        self.ctx.call("uwip_dehaze_histretch", C.byref(sb), C.byref(ob), self.w, DEHAZE_FULL | DEHAZE_GUARD_S,
+                      self.letters, 2, 98, 0)
+
     def stage_aclahe(self):
         wb, vb, ob = batch_of(self.work), batch_of(self.v), batch_of(self.v_out)
         self.ctx.call("uwip_bgr_to_v", C.byref(wb), C.byref(vb))
@@ -108,8 +114,7 @@ class FramePipe:
         self.ctx.d2h_async(h_out, self.work)
 
     def run(self, src: torch.Tensor):
-        self.stage_dehaze(src)
-        self.stage_histretch()
+        self.stage_dehaze_histretch(src)
         self.stage_aclahe()
         self.stage_overlap()
         return self.work, self.ratio
