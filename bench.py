@@ -187,13 +187,14 @@ STAGE_OF = [("k_ov_", "overlap"), ("k_hist_u8", "histretch"), ("k_compose_luts",
             ("k_apply_lut", "histretch"), ("k_bgr_to_v", "aclahe"), ("k_clahe_", "aclahe"), ("k_entropy", "aclahe"),
             ("k_hsv_replace_v", "aclahe"), ("k_gauss3", "aclahe")]
 # SURVEY.md 8(d) algorithmic bytes per pixel (N = W*H):
-#   histretch "RGB": read 3N (hist) + read 3N + write 3N (apply)                                        =   9 N
+#   histretch "RGB": read 3N + write 3N (apply).  SURVEY 8(d) also counts a 3N histogram read; in the chained call
+#           the dehaze writer counts its own bytes (k_exp_out<1,HIST>), so that read does not happen          =   6 N
 #   aclahe: sweep minimum 5 grids x 2N + final apply 3N = 13 N (8d), plus the colour conversions around it
 #           (BGR -> V: 3N + N; HSV merge: 3N + N read, 3N write)                                         =  24 N
 #   bgdehaze, from the implemented float64 pass list: k_winfilter15 3+6, k_bglight 3,
 #           filter 1 solve 3+2+64, final 64+3+16, k_exp_prep 3+16+3+1, k_exp_S 3+1+8, filter 3 solve 3+8+32,
 #           final 32+3+8, k_exp_out pass 0 3+16+8, pass 1 3+16+8+3                                       = 342 N
-STAGE_BYTES_PER_PIXEL = {"histretch": 9.0, "aclahe": 24.0, "bgdehaze": 342.0}
+STAGE_BYTES_PER_PIXEL = {"histretch": 6.0, "aclahe": 24.0, "bgdehaze": 342.0}
 
 
 def stage_of(kernel):

@@ -177,6 +177,10 @@ int uwip_entropy(uwip_ctx *ctx, const uwip_batch_u8 *src, float *d_entropy);
  * {0,0.5,...,25}; d_entropy: [frames][5][51] float (clean table). */
 int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int residual_rule,
                       float *d_entropy);
+/* The same with a tap (may be NULL): d_hist [frames][5][51][256] uint32, the histogram of the CLAHE output of every
+ * (grid, clip limit) -- what calcHist sees at aclahe.cpp:236 -- for exact parity checks of the sweep. */
+int uwip_aclahe_sweep_hist(uwip_ctx *ctx, const uwip_batch_u8 *src, int residual_rule,
+                           float *d_entropy, uint32_t *d_hist);
 
 /* Parameter choice of modules/aclahe/python/ACLAHE.py:66-129 (host, pure; the
  * reference does it with scipy, functions.py:49-93; the C++ module stops at

@@ -99,6 +99,53 @@ def test_sweep_vs_oracle(ctx, orc, shape):
         assert np.abs(tab[f] - exp).max() <= 1e-5, np.abs(tab[f] - exp).max()
 
 
+def _mixed_plane(seed, rows, cols):
+    """Regions whose tile histograms stop being clipped at different clip limits: 6 grey levels (every limit clips),
+    ~20 levels (only the limits of the last group repeat), ~40 levels, white noise (nothing clips beyond the first few
+    limits), a constant patch; region borders do not follow any tile grid."""
+    rng = np.random.default_rng(seed)
+    v = np.empty((rows, cols), np.uint8)
+    xs = [0, cols * 3 // 11, cols * 5 // 11, cols * 8 // 11, cols]
+    v[:, xs[0]:xs[1]] = rng.integers(0, 6, (rows, xs[1] - xs[0])) * 40 + 10
+    v[:, xs[1]:xs[2]] = rng.integers(0, 20, (rows, xs[2] - xs[1])) * 12 + 3
+    v[:, xs[2]:xs[3]] = rng.integers(0, 256, (rows, xs[3] - xs[2]))
+    v[:, xs[3]:xs[4]] = rng.integers(0, 40, (rows, xs[4] - xs[3])) * 6
+    v[rows // 3: rows // 2, cols // 4: cols // 2] = 77
+    return v
+
+
+@pytest.mark.parametrize("shape", [(96, 160), (270, 480), (301, 517)])
+def test_sweep_histograms_exact_vs_oracle(ctx, orc, shape):
+    """Every one of the 255 output histograms, count for count: the kernel evaluates a clip limit only where its LUTs
+    differ from the previous limit's and books the repeats through tail / group counters, so the check is on the
+    counts themselves (an entropy tolerance would hide single pixels)."""
+    frames = np.stack([_mixed_plane(5, *shape), _v(orc, 61, *shape)])
+    ent, hist = aclahe.sweep_histograms(ctx, _dev(frames))
+    hist = hist.cpu().numpy()
+    assert torch.equal(ent, aclahe.sweep(ctx, _dev(frames)))
+    for f in range(2):
+        for gi, g in enumerate(aclahe.BLOCK_SIZES):
+            for ci, cl in enumerate(aclahe.CLIP_LIMITS):
+                exp = np.bincount(orc.clahe(frames[f], float(cl), g, g).ravel(), minlength=256)
+                assert np.array_equal(hist[f, gi, ci], exp), (f, g, cl)
+
+
+def test_sweep_histograms_exact_1080p(ctx, orc):
+    """Full size: the tap against the histogram of this library's own (oracle-exact) CLAHE apply, for limits of all three
+    clip-limit groups on every grid, on a bench-like frame and on the mixed-region plane."""
+    for src in (_v(orc, 70, 1080, 1920), _mixed_plane(9, 1080, 1920)):
+        t = _dev(src)
+        _, hist = aclahe.sweep_histograms(ctx, t)
+        assert int(hist.sum(dim=-1).min()) == 1080 * 1920 and int(hist.sum(dim=-1).max()) == 1080 * 1920
+        c = aclahe.CLAHE(ctx)
+        for gi, g in enumerate(aclahe.BLOCK_SIZES):
+            c.setTilesGridSize((g, g))
+            for ci in (0, 1, 9, 16, 17, 25, 33, 34, 42, 50):
+                c.setClipLimit(aclahe.CLIP_LIMITS[ci])
+                exp = torch.bincount(c.apply(t).flatten().to(torch.int64), minlength=256)
+                assert torch.equal(hist[0, gi, ci].to(torch.int64), exp), (g, ci)
+
+
 def test_sweep_1080p_properties(ctx, orc):
     # full-size: the sweep's histograms must equal those of materialised CLAHE outputs
     # (checked through entropy of our own bit-exact CLAHE apply), and spot-check the oracle

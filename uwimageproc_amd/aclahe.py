@@ -126,6 +126,17 @@ def sweep(ctx: Context, plane: torch.Tensor, residual_rule: int = 0) -> torch.Te
     return out
 
 
+def sweep_histograms(ctx: Context, plane: torch.Tensor, residual_rule: int = 0):
+    """The sweep with its tap: (entropy [frames, 5, 51], histograms [frames, 5, 51, 256] of every CLAHE output)."""
+    b = batch_of(plane)
+    out = torch.empty((b.frames, 5, 51), dtype=torch.float32, device=plane.device)
+    hist = torch.empty((b.frames, 5, 51, 256), dtype=torch.int32, device=plane.device)
+    _pre(plane)
+    ctx.call("uwip_aclahe_sweep_hist", C.byref(b), int(residual_rule), C.c_void_p(out.data_ptr()), C.c_void_p(hist.data_ptr()))
+    ctx.sync()
+    return out, hist
+
+
 # ---------------------------------------------------------------------------
 # C4: parameter selection, modules/aclahe/python/ACLAHE.py:66-129 +
 # functions.py:49-93.  The reference does this on the host with scipy; so does

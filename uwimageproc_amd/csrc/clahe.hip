@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void k_clahe_tilehist_merge(const uint32_t *__
 __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ hists, int tiles, int nf,
                                                    float lutScale, ClipList cl,
                                                    const int *__restrict__ frame_clip, int rule,
-                                                   uint8_t *__restrict__ luts)
+                                                   uint8_t *__restrict__ luts, uint32_t *__restrict__ tile_max /*optional*/)
 {
     const int lane = threadIdx.x & 63;
     const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -237,6 +237,13 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
     const uint4 hv = *reinterpret_cast<const uint4 *>(hists + ((size_t)f * tiles + t) * 256 + lane * 4);
     const int h0[4] = {(int)hv.x, (int)hv.y, (int)hv.z, (int)hv.w};
     const int ncl = cl.n;
+    if (tile_max) {
+        // the tile's tallest bin: a clip limit at or above it clips nothing (k_clahe_sweep skips such limits)
+        int m = max(max(h0[0], h0[1]), max(h0[2], h0[3]));
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
+        if (lane == 0) tile_max[(size_t)f * tiles + t] = (uint32_t)m;
+    }
     for (int c = 0; c < ncl; ++c) {
         const int clip = frame_clip ? frame_clip[f] : cl.clip[c];
         int h[4] = {h0[0], h0[1], h0[2], h0[3]};
@@ -418,6 +425,18 @@ constexpr int SWEEP_REP = 3;
 constexpr int SWEEP_HROWS = (SWEEP_GROUP + 1) / 2;   // two clip limits share a word: 16-bit counters (a block sees < 65536 pixels)
 constexpr int SWEEP_SPREAD = 8;    // multiple of SWEEP_THREADS / 64
 constexpr int SWEEP_RSTRIDE = SWEEP_HROWS * 256 + 8;   // +8 words: equal bins of different replicas fall in different LDS banks
+// A clip limit at or above the tallest bin of a cell's four tiles clips nothing: the 17 limits of a group therefore give
+// `nd` different LUTs followed by 17 - nd repeats of the last one (clip limits grow with their index).  The repeats are
+// never evaluated: the pixel's output under limit nd-1 is counted ONCE, in a tail histogram T[nd-1], and the flush adds
+// T[0..c] to H[c].  (T[16] does not exist: nd = 17 has no repeats.)  One copy, 16-bit counter pairs like H.
+constexpr int SWEEP_TROWS = (SWEEP_GROUP - 1) / 2;
+// Whole groups of repeats are not even walked: when limit 16 (33) already clips nothing in a cell, every limit of group 1
+// (2) gives the outputs of limit 0, the unclipped LUT.  The block of group 0 counts those once more in G and adds G to
+// the rows of groups 1 / 2 at flush time; the blocks of groups 1 / 2 skip the cell.  G lives in the one counter slot H
+// leaves free (the high half of row 8: 17 limits in 18 slots): replica 0 for cells where groups 1 and 2 repeat, replica 1
+// for cells where only group 2 does.
+constexpr size_t SWEEP_LDS_WORDS = (size_t)SWEEP_GROUP * 256 + (size_t)SWEEP_REP * SWEEP_RSTRIDE + (size_t)SWEEP_TROWS * 256;
+static_assert(SWEEP_REP >= 2 && (SWEEP_GROUP & 1) == 1 && SWEEP_LDS_WORDS * 4 + 128 <= 54528, "three blocks per CU (tools/ubench/lds_occ.hip: 54528 B is the most LDS a block of three may hold)");
 // (TL*xa1 + TR*xa)*ya1 + (BL*xa1 + BR*xa)*ya -> RNE, clamped byte; pk = TL | TR << 8 | BL << 16 | BR << 24.
 // Plain f32 multiplies and adds in OpenCV's order (no FMA): on gfx950 a v_pk_mul/add_f32 costs 2.6x a v_mul/add_f32
 // (tools/ubench/valu_rate.hip: 2.97 vs 1.14 ns per wave-instruction), so the two-rows-per-packed-pair form lost.
@@ -428,6 +447,18 @@ __device__ __forceinline__ uint32_t sweep_eval(uint32_t pk, float xa1, float xa,
     return __builtin_amdgcn_cvt_pk_u8_f32(top * ya1 + bot * ya, 0, 0u);     // RNE + clamp
 }
 
+// clip limits K0 .. K0+N-1 of one pixel: the N LUT reads go out together, their evaluations interleave
+template <int K0, int N>
+__device__ __forceinline__ void sweep_run(const uint32_t *pack_v, uint32_t *my_hist, float xa1, float xa, float ya1, float ya)
+{
+    uint32_t pk[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) pk[i] = pack_v[(K0 + i) * 256];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        atomicAdd(&my_hist[((K0 + i) >> 1) * 256 + sweep_eval(pk[i], xa1, xa, ya1, ya)], ((K0 + i) & 1) ? 65536u : 1u);
+}
+
 __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__restrict__ src, size_t step,
                                                      size_t fstride, int gx, int gy, float inv_tw,
                                                      float inv_th,
@@ -435,26 +466,46 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
                                                      const CellItem *__restrict__ items, int nitems,
                                                      int items_per_block,
                                                      uint32_t *__restrict__ out_hist /*[F][51][256]*/,
-                                                     size_t out_fs)
+                                                     size_t out_fs, const uint32_t *__restrict__ tile_max /*[F][tiles]*/,
+                                                     int clip_g1, int clip_g2)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_sweep[];
     uint32_t *s_pack = s_sweep;                                   // [SWEEP_GROUP][256]
     uint32_t *s_hist = s_sweep + SWEEP_GROUP * 256;               // [SWEEP_REP][SWEEP_HROWS][256], two 16-bit counters per word
+    uint32_t *s_tail = s_hist + SWEEP_REP * SWEEP_RSTRIDE;        // [SWEEP_TROWS][256], same packing
     __shared__ uint32_t s_diff[SWEEP_GROUP];
     const int tid = threadIdx.x;
     const int cg = blockIdx.y, f = blockIdx.z;
     const int tiles = gx * gy;
-    for (int i = tid; i < SWEEP_REP * SWEEP_RSTRIDE; i += SWEEP_THREADS) s_hist[i] = 0;
+    const uint32_t *tmax = tile_max + (size_t)f * tiles;
+    const int i0 = blockIdx.x * items_per_block, i1 = min(nitems, i0 + items_per_block);
+    if (cg != 0) {
+        // nothing to do when every cell of this block repeats limit 0 throughout the group (block-uniform)
+        const uint32_t clip_prev = (uint32_t)(cg == 1 ? clip_g1 : clip_g2);
+        bool any = false;
+        for (int it = i0; it < i1; ++it) {
+            const CellItem ci = items[it];
+            const int tx1 = max(ci.cx - 1, 0), tx2 = min(ci.cx, gx - 1), ty1 = max(ci.cy - 1, 0), ty2 = min(ci.cy, gy - 1);
+            any = any || clip_prev < max(max(tmax[ty1 * gx + tx1], tmax[ty1 * gx + tx2]), max(tmax[ty2 * gx + tx1], tmax[ty2 * gx + tx2]));
+        }
+        if (!any) return;
+    }
+    for (int i = tid; i < SWEEP_REP * SWEEP_RSTRIDE + SWEEP_TROWS * 256; i += SWEEP_THREADS) s_hist[i] = 0;
     uint32_t *my_hist = s_hist + (tid % SWEEP_REP) * SWEEP_RSTRIDE;
     const uint8_t *fb = src + (size_t)f * fstride;
     const uint8_t *L = luts + ((size_t)f * SWEEP_NCL + (size_t)cg * SWEEP_GROUP) * tiles * 256;
-    const int i0 = blockIdx.x * items_per_block, i1 = min(nitems, i0 + items_per_block);
     const bool single = (i1 - i0) == 1;
     uint32_t last_mask = 0xffffffffu;
+    bool copy_at_flush = false;
     for (int it = i0; it < i1; ++it) {
         const CellItem ci = items[it];
         const int tx1 = max(ci.cx - 1, 0), tx2 = min(ci.cx, gx - 1);
         const int ty1 = max(ci.cy - 1, 0), ty2 = min(ci.cy, gy - 1);
+        const uint32_t cellmax = max(max(tmax[ty1 * gx + tx1], tmax[ty1 * gx + tx2]), max(tmax[ty2 * gx + tx1], tmax[ty2 * gx + tx2]));
+        const bool rep1 = (uint32_t)clip_g1 >= cellmax, rep2 = (uint32_t)clip_g2 >= cellmax;   // rep1 implies rep2
+        if ((cg == 1 && rep1) || (cg == 2 && rep2)) continue;            // counted by the block of group 0 (block-uniform)
+        const bool g_any = cg == 0 && rep2, g_both = cg == 0 && rep1;
+        uint32_t *s_g = s_hist + (g_both ? 0 : SWEEP_RSTRIDE) + (SWEEP_HROWS - 1) * 256;
         __syncthreads();
         // four grey levels per thread: one dword from each of the four tiles' LUTs, byte-transposed by v_perm into
         // four packed entries (TL | TR << 8 | BL << 16 | BR << 24) and stored as one 16-byte LDS write
@@ -485,6 +536,14 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
         for (int c = 0; c < SWEEP_GROUP; ++c) diffmask |= (s_diff[c] ? 1u : 0u) << c;
         diffmask = __builtin_amdgcn_readfirstlane(diffmask);
         last_mask = diffmask;
+        // nd leading limits with LUTs of their own, then repeats only (the rule); anything else (two limits that still clip
+        // but round to one LUT) takes the general path below
+        const bool prefix = ((diffmask + 1u) & diffmask) == 0u;
+        const int ns = __builtin_popcount(diffmask) - 1;          // limits 0 .. ns-1 go to H, limit ns to T[ns] (block-uniform)
+        if (!prefix && single) copy_at_flush = true;
+        // with rep1 the last distinct limit of a prefix cell is the unclipped LUT itself: its output is reused for G
+        const bool g_last = g_both && prefix && diffmask != (1u << SWEEP_GROUP) - 1u;
+        const bool g_sep = g_any && !g_last;
         const int w = ci.x1 - ci.x0;
         const int npix = w * (ci.r1 - ci.r0);
         const float inv_w = 1.0f / (float)w;
@@ -526,15 +585,43 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
             const float xa = txf - floorf(txf), xa1 = 1.0f - xa;
             const float tyf = (float)y * inv_th - 0.5f;
             const float ya = tyf - floorf(tyf), ya1 = 1.0f - ya;
+            const uint32_t *pack_v = s_pack + v;
+            if (g_sep) atomicAdd(&s_g[sweep_eval(pack_v[0], xa1, xa, ya1, ya)], 65536u);
             if (diffmask == (1u << SWEEP_GROUP) - 1u) {
-                // every clip limit has its own LUTs (the common case): no branches, so the 17 LUT reads go out
-                // together and their evaluations interleave
-                uint32_t pk[SWEEP_GROUP];
-#pragma unroll
-                for (int c = 0; c < SWEEP_GROUP; ++c) pk[c] = s_pack[c * 256 + v];
-#pragma unroll
-                for (int c = 0; c < SWEEP_GROUP; ++c)
-                    atomicAdd(&my_hist[(c >> 1) * 256 + sweep_eval(pk[c], xa1, xa, ya1, ya)], (c & 1) ? 65536u : 1u);
+                sweep_run<0, SWEEP_GROUP>(pack_v, my_hist, xa1, xa, ya1, ya);      // every clip limit has its own LUTs
+                continue;
+            }
+            if (prefix) {
+                // ns evaluations in straight-line runs of 8 / 4 / 2 / 1 (ns < 16), then the last distinct limit into the tail
+                const uint32_t pk_last = pack_v[ns * 256];
+                if (ns & 8) sweep_run<0, 8>(pack_v, my_hist, xa1, xa, ya1, ya);
+                if (ns & 4) {
+                    if (ns & 8) sweep_run<8, 4>(pack_v, my_hist, xa1, xa, ya1, ya);
+                    else sweep_run<0, 4>(pack_v, my_hist, xa1, xa, ya1, ya);
+                }
+                if (ns & 2) {
+                    switch (ns & 12) {
+                    case 0: sweep_run<0, 2>(pack_v, my_hist, xa1, xa, ya1, ya); break;
+                    case 4: sweep_run<4, 2>(pack_v, my_hist, xa1, xa, ya1, ya); break;
+                    case 8: sweep_run<8, 2>(pack_v, my_hist, xa1, xa, ya1, ya); break;
+                    default: sweep_run<12, 2>(pack_v, my_hist, xa1, xa, ya1, ya); break;
+                    }
+                }
+                if (ns & 1) {
+                    switch (ns & 14) {
+                    case 0: sweep_run<0, 1>(pack_v, my_hist, xa1, xa, ya1, ya); break;
+                    case 2: sweep_run<2, 1>(pack_v, my_hist, xa1, xa, ya1, ya); break;
+                    case 4: sweep_run<4, 1>(pack_v, my_hist, xa1, xa, ya1, ya); break;
+                    case 6: sweep_run<6, 1>(pack_v, my_hist, xa1, xa, ya1, ya); break;
+                    case 8: sweep_run<8, 1>(pack_v, my_hist, xa1, xa, ya1, ya); break;
+                    case 10: sweep_run<10, 1>(pack_v, my_hist, xa1, xa, ya1, ya); break;
+                    case 12: sweep_run<12, 1>(pack_v, my_hist, xa1, xa, ya1, ya); break;
+                    default: sweep_run<14, 1>(pack_v, my_hist, xa1, xa, ya1, ya); break;
+                    }
+                }
+                const uint32_t o_last = sweep_eval(pk_last, xa1, xa, ya1, ya);
+                atomicAdd(&s_tail[(ns >> 1) * 256 + o_last], (ns & 1) ? 65536u : 1u);
+                if (g_last) atomicAdd(&s_g[o_last], 65536u);
                 continue;
             }
             uint32_t o = 0;
@@ -551,6 +638,28 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
     }
     __syncthreads();
     uint32_t *out = out_hist + (size_t)f * out_fs + (size_t)cg * SWEEP_GROUP * 256;
+    if (!copy_at_flush) {
+        // H[c] + T[0] + ... + T[min(c, 15)], one thread per grey level walking up the clip limits
+        if (tid < 256) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int c = 0; c < SWEEP_GROUP; ++c) {
+                const int sh = (c & 1) * 16;
+                if (c < SWEEP_GROUP - 1) run += (s_tail[(c >> 1) * 256 + tid] >> sh) & 0xffffu;
+                uint32_t sum = run;
+#pragma unroll
+                for (int r = 0; r < SWEEP_REP; ++r) sum += (s_hist[r * SWEEP_RSTRIDE + (c >> 1) * 256 + tid] >> sh) & 0xffffu;
+                if (sum) atomicAdd(&out[c * 256 + tid], sum);
+            }
+        }
+    }
+    if (cg == 0 && tid < 256) {
+        const uint32_t g1 = s_hist[(SWEEP_HROWS - 1) * 256 + tid] >> 16;
+        const uint32_t g2 = g1 + (s_hist[SWEEP_RSTRIDE + (SWEEP_HROWS - 1) * 256 + tid] >> 16);
+        if (g1) for (int c = SWEEP_GROUP; c < 2 * SWEEP_GROUP; ++c) atomicAdd(&out[c * 256 + tid], g1);
+        if (g2) for (int c = 2 * SWEEP_GROUP; c < 3 * SWEEP_GROUP; ++c) atomicAdd(&out[c * 256 + tid], g2);
+    }
+    if (!copy_at_flush) return;
     for (int i = tid; i < SWEEP_GROUP * 256; i += SWEEP_THREADS) {
         int src = i;
         if (single) {
@@ -608,11 +717,11 @@ int launch_tilehist(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g,
 }
 
 int launch_lut(uwip_ctx *ctx, const ClaheGeom &g, const uint32_t *d_hists, const ClipList &cl,
-               const int *d_frame_clip, int nf, int rule, uint8_t *d_luts)
+               const int *d_frame_clip, int nf, int rule, uint8_t *d_luts, uint32_t *d_tile_max = nullptr)
 {
     const int tiles = g.gx * g.gy;
     uwip_kscope ks(ctx, "k_clahe_lut");
-    k_clahe_lut<<<uwip_cdiv((size_t)tiles * nf, 4), 256, 0, ctx->stream>>>(d_hists, tiles, nf, g.lutScale, cl, d_frame_clip, rule, d_luts);
+    k_clahe_lut<<<uwip_cdiv((size_t)tiles * nf, 4), 256, 0, ctx->stream>>>(d_hists, tiles, nf, g.lutScale, cl, d_frame_clip, rule, d_luts, d_tile_max);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
@@ -920,7 +1029,7 @@ UWIP_API int uwip_entropy(uwip_ctx *ctx, const uwip_batch_u8 *src, float *d_entr
     return UWIP_OK;
 }
 
-UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int residual_rule, float *d_entropy)
+UWIP_API int uwip_aclahe_sweep_hist(uwip_ctx *ctx, const uwip_batch_u8 *src, int residual_rule, float *d_entropy, uint32_t *d_hist_tap)
 {
     static const int BlockSize[5] = {2, 4, 8, 16, 32};          // aclahe.cpp:161
     int rc = uwip_check_batch(ctx, src, 1);
@@ -940,7 +1049,8 @@ UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int resi
     uint32_t *hbuf[2] = {(uint32_t *)uwip_ws(ctx, "clahe.tilehist", sizeof(uint32_t) * 256 * (size_t)1024 * F),
                          (uint32_t *)uwip_ws(ctx, "clahe.tilehist2", sizeof(uint32_t) * 256 * (size_t)1024 * F)};
     uint8_t *d_luts = (uint8_t *)uwip_ws(ctx, "sweep.luts", (size_t)256 * 1024 * SWEEP_NCL * F);
-    if (!d_out || !hbuf[0] || !hbuf[1] || !d_luts) return UWIP_ERR_NOMEM;
+    uint32_t *d_tmax = (uint32_t *)uwip_ws(ctx, "sweep.tilemax", sizeof(uint32_t) * (size_t)1024 * F);
+    if (!d_out || !hbuf[0] || !hbuf[1] || !d_luts || !d_tmax) return UWIP_ERR_NOMEM;
     UWIP_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(uint32_t) * out_fs * F, ctx->stream));
     // finest grid first: a coarser unpadded grid sums the tile histograms of the grid twice as fine
     ClaheGeom finer{};
@@ -962,7 +1072,7 @@ UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int resi
         ClipList cl{};
         cl.n = 0;
         for (float c = 0.0f; c <= 25.0f; c += 0.5f) cl.clip[cl.n++] = clip_from_limit((double)c, g.area);
-        rc = launch_lut(ctx, g, d_hists, cl, nullptr, F, residual_rule, d_luts);
+        rc = launch_lut(ctx, g, d_hists, cl, nullptr, F, residual_rule, d_luts, d_tmax);
         if (rc) return rc;
         // work items: interpolation cells cut into row chunks of <= ~16K pixels (cached per geometry)
         char key[96];
@@ -997,12 +1107,13 @@ UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int resi
         const int ipb = std::max(1, std::min(32, 32768 / cell_px));   // <= 32768 pixels per block: the 16-bit LDS counters cannot overflow
         dim3 grid(uwip_cdiv(nitems, ipb), SWEEP_NCL / SWEEP_GROUP, (unsigned)F);
         uwip_kscope ks(ctx, "k_clahe_sweep");
-        const size_t sweep_lds = sizeof(uint32_t) * ((size_t)SWEEP_GROUP * 256 + (size_t)SWEEP_REP * SWEEP_RSTRIDE);
+        const size_t sweep_lds = sizeof(uint32_t) * SWEEP_LDS_WORDS;
         rc = uwip_lds_optin(ctx, "k_clahe_sweep", (const void *)k_clahe_sweep, sweep_lds);
         if (rc) return rc;
         k_clahe_sweep<<<grid, SWEEP_THREADS, sweep_lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.gx,
                                                      g.gy, g.inv_tw, g.inv_th, d_luts, d_items, nitems, ipb,
-                                                     d_out + (size_t)gi * SWEEP_NCL * 256, out_fs);
+                                                     d_out + (size_t)gi * SWEEP_NCL * 256, out_fs, d_tmax,
+                                                     cl.clip[SWEEP_GROUP - 1], cl.clip[2 * SWEEP_GROUP - 1]);
         UWIP_HIP(ctx, hipGetLastError());
     }
     {
@@ -1010,7 +1121,13 @@ UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int resi
         k_entropy<<<F * 5 * SWEEP_NCL, 256, 0, ctx->stream>>>(d_out, src->rows, src->cols, d_entropy);
         UWIP_HIP(ctx, hipGetLastError());
     }
+    if (d_hist_tap) UWIP_HIP(ctx, hipMemcpyAsync(d_hist_tap, d_out, sizeof(uint32_t) * out_fs * F, hipMemcpyDeviceToDevice, ctx->stream));
     return UWIP_OK;
+}
+
+UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int residual_rule, float *d_entropy)
+{
+    return uwip_aclahe_sweep_hist(ctx, src, residual_rule, d_entropy, nullptr);
 }
 
 int uwip_aclahe_select_internal(const float *h_entropy, int frames, int32_t *h_bs, int32_t *h_cl, int32_t *h_knee,
