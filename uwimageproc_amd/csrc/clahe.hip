@@ -237,17 +237,24 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
     const uint4 hv = *reinterpret_cast<const uint4 *>(hists + ((size_t)f * tiles + t) * 256 + lane * 4);
     const int h0[4] = {(int)hv.x, (int)hv.y, (int)hv.z, (int)hv.w};
     const int ncl = cl.n;
-    if (tile_max) {
-        // the tile's tallest bin: a clip limit at or above it clips nothing (k_clahe_sweep skips such limits)
-        int m = max(max(h0[0], h0[1]), max(h0[2], h0[3]));
+    // the tile's tallest bin: a clip limit at or above it clips nothing (cv::CLAHE clips bins > limit only), so its LUT is
+    // the unclipped one -- computed once here, and k_clahe_sweep never evaluates such limits
+    int m = max(max(h0[0], h0[1]), max(h0[2], h0[3]));
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
-        if (lane == 0) tile_max[(size_t)f * tiles + t] = (uint32_t)m;
-    }
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
+    if (tile_max && lane == 0) tile_max[(size_t)f * tiles + t] = (uint32_t)m;
+    auto lut_word = [&](const int h[4]) {
+        const int p0 = h[0], p1 = p0 + h[1], p2 = p1 + h[2], p3 = p2 + h[3];
+        const int off = (int)wave_incl_scan_u32((uint32_t)p3) - p3;
+        return sat_u8_rne((float)(off + p0) * lutScale) | (sat_u8_rne((float)(off + p1) * lutScale) << 8) |
+               (sat_u8_rne((float)(off + p2) * lutScale) << 16) | (sat_u8_rne((float)(off + p3) * lutScale) << 24);
+    };
+    const uint32_t w_unclipped = lut_word(h0);
     for (int c = 0; c < ncl; ++c) {
         const int clip = frame_clip ? frame_clip[f] : cl.clip[c];
-        int h[4] = {h0[0], h0[1], h0[2], h0[3]};
-        if (clip > 0) {
+        uint32_t w = w_unclipped;
+        if (clip > 0 && clip < m) {                                    // wave-uniform
+            int h[4] = {h0[0], h0[1], h0[2], h0[3]};
             int excess = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) { excess += max(h[k] - clip, 0); h[k] = min(h[k], clip); }
@@ -270,11 +277,8 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
                     } else if (v < residual) h[k]++;                                           // OpenCV 3.2
                 }
             }
+            w = lut_word(h);
         }
-        const int p0 = h[0], p1 = p0 + h[1], p2 = p1 + h[2], p3 = p2 + h[3];
-        const int off = (int)wave_incl_scan_u32((uint32_t)p3) - p3;
-        const uint32_t w = sat_u8_rne((float)(off + p0) * lutScale) | (sat_u8_rne((float)(off + p1) * lutScale) << 8) |
-                           (sat_u8_rne((float)(off + p2) * lutScale) << 16) | (sat_u8_rne((float)(off + p3) * lutScale) << 24);
         *reinterpret_cast<uint32_t *>(luts + (((size_t)f * ncl + c) * tiles + t) * 256 + lane * 4) = w;
     }
 }
