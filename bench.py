@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matcher-bench", dest="matcher_bench", action="store_false",
                     help="skip the 2048 x 2048 matcher measurement (MFMA utilisation on BASELINE config 4's size)")
+    ap.add_argument("--no-large-working-set", dest="large_ws", action="store_false",
+                    help="skip the 1 GB single-launch measurement of k_clahe_apply (profiling runs: keeps the counter averages of "
+                         "that kernel to the step's own launches)")
     ap.add_argument("--no-host-buffers", dest="host_buffers", action="store_false",
                     help="skip the upload/download-inclusive variant (timed on rank 0 after the main region)")
     a = ap.parse_args()
@@ -180,7 +183,12 @@ def cpu_baseline(H, W):
 
 
 I8_MFMA_PEAK_TOPS = 5000.0     # dense i8 = 2x the ~2.5 PFLOP/s dense BF16 rate (MI355X_MICROARCH.md, Matrix cores)
-VALU_PEAK_GINSTR = 1024 * 2.4 / 4.0   # 1024 SIMDs, one wave64 VALU instruction per 4 clocks at the 2.4 GHz max clock
+# VALU issue: 1024 SIMDs.  The f32 rate in MI355X_MICROARCH.md (157 TFLOP/s vector f32 = 128 FMA lanes per CU and clock)
+# is one wave64 instruction per SIMD every 2 clocks = 1229 G wave-instr/s at 2.4 GHz; on this chip a dependent-free
+# stream of v_mul/v_add/v_fma_f32 issues one per 1.14 ns per SIMD (tools/ubench/valu_rate.hip) = 898 G/s, and the
+# conversions / byte permutes / shift-adds the CLAHE kernels are made of take 1.83 ns.
+VALU_SPEC_GINSTR = 1024 * 2.4 / 2.0
+VALU_PEAK_GINSTR = 1024 / 1.14
 
 # kernel name -> stage of the pipe
 STAGE_OF = [("k_ov_", "overlap"), ("k_hist_u8", "histretch"), ("k_compose_luts", "histretch"), ("k_stretch_lut", "histretch"),
@@ -290,6 +298,8 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
     # 1080p frames = 1.06 GB), input last touched a whole buffer ago
     big_f = max(Fs, int(np.ceil(1.0e9 / (2.0 * N))))
     try:
+        if not args.large_ws:
+            raise RuntimeError("skipped (--no-large-working-set)")
         vin = torch.randint(0, 256, (big_f, H, W), dtype=torch.uint8, device=dev)
         vout = torch.empty_like(vin)
         ib, ob = batch_of(vin), batch_of(vout)
@@ -327,9 +337,13 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
         ginstr = e["valu_insts_per_frame"] * Fs / ((dms / dcnt) * 1e-3) / 1e9          # every launch covers the whole sub-batch
         dom["valu"] = {"wave_instr_per_launch": e["valu_insts_per_frame"] * Fs, "achieved_Ginstr_per_s": ginstr,
                        "peak_Ginstr_per_s": VALU_PEAK_GINSTR, "frac": ginstr / VALU_PEAK_GINSTR,
-                       "source": "SQ_INSTS_VALU of the committed rocprofv3 --pmc pass (profiles/), time from this run; the peak assumes "
-                                 "one wave64 instruction per 4 clocks per SIMD at 2.4 GHz (measured: v_mul/add_f32 issue in 1.14 ns, "
-                                 "v_cvt / v_perm / address ops in 1.83 ns, v_pk_*_f32 in 2.97 ns: tools/ubench/valu_rate.hip)"}
+                       "spec_peak_Ginstr_per_s": VALU_SPEC_GINSTR, "frac_of_spec": ginstr / VALU_SPEC_GINSTR,
+                       "mean_ns_per_instr_per_simd": 1024.0 / ginstr,
+                       "source": "SQ_INSTS_VALU of the committed rocprofv3 --pmc pass (profiles/), time from this run.  peak = the "
+                                 "measured issue rate of plain f32 operations (one per 1.14 ns per SIMD, tools/ubench/valu_rate.hip); "
+                                 "the kernel's mix also holds v_cvt_f32_ubyte / v_cvt_pk_u8_f32 / v_lshl_add at 1.83 ns, so "
+                                 "mean_ns_per_instr_per_simd against 1.14 .. 1.83 says how busy the issue port is; spec_peak = one "
+                                 "wave64 f32 instruction per 2 clocks at 2.4 GHz (128 FMA lanes per CU and clock)"}
     roof["dominant"] = dom
     # (3) per stage: kernel time against the stage's 8(d) algorithmic bytes
     stages = {}
