@@ -422,8 +422,9 @@ struct CellItem {
 
 // Same-bin LDS atomics from one wave serialise, and neighbouring pixels of a smooth underwater frame land in
 // few bins: the output histograms are therefore replicated SWEEP_REP times, keyed by the thread index modulo
-// SWEEP_REP.  A block is 512 threads; packed LUTs (17 KB) + 3 replicas of 16-bit counters (27 KB) = 45 KB of LDS,
-// three blocks per CU (measured: 2 replicas x 4 blocks and 4 replicas x 2 blocks are both slower).
+// SWEEP_REP.  A block is 512 threads; packed LUTs (17 KB) + 3 replicas of 16-bit counters (27 KB) + the tail
+// histograms (8 KB, below) = 52 KB of LDS, three blocks per CU (measured: 2 replicas x 4 blocks and 4 replicas x 2
+// blocks are both slower).
 constexpr int SWEEP_THREADS = 512;
 constexpr int SWEEP_REP = 3;
 constexpr int SWEEP_HROWS = (SWEEP_GROUP + 1) / 2;   // two clip limits share a word: 16-bit counters (a block sees < 65536 pixels)
