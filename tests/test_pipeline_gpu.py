@@ -228,7 +228,7 @@ def test_host_buffer_front_end_equals_device_path():
         for _ in range(2):
             pipes[i].have_prev = False
             pipes[i].run_host(*bufs[i])
-        pipes[i].ctx.sync()
+        pipes[i].sync()
     th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
     for t in th:
         t.start()
@@ -240,6 +240,42 @@ def test_host_buffer_front_end_equals_device_path():
         for a in bufs[i]:
             pipes[i].ctx.host_free(a)
         pipes[i].close()
+
+
+def test_host_buffer_front_end_prefetched_batches():
+    """A stream of different batches through run_host with the next batch prefetched (upload and download on their own
+    streams, two source and two result buffers): every downloaded batch equals the HBM-resident path's result, and the
+    overlap ratios carry across the batches as they do there."""
+    F, H, W, NB = 2, 270, 480, 5
+    batches = [synth.uw_stream(F * b, F, H, W) for b in range(NB)]
+    ref_pipe = FramePipe(0, F, H, W, video_size=(640, 480))
+    ref = []
+    for b in range(NB):
+        out, ratio = ref_pipe.run(torch.from_numpy(batches[b]).cuda())
+        torch.cuda.synchronize()
+        ref.append((out.cpu().numpy().copy(), ratio.cpu().numpy().copy()))
+    ref_pipe.close()
+    with torch.cuda.stream(torch.cuda.Stream()):
+        pipe = FramePipe(0, F, H, W, video_size=(640, 480))
+    h_in = [pipe.ctx.host_alloc((F, H, W, 3)) for _ in range(NB)]
+    h_out = [pipe.ctx.host_alloc((F, H, W, 3)) for _ in range(NB)]
+    for b in range(NB):
+        h_in[b][...] = batches[b]
+        h_out[b][...] = 0
+    ratios = []
+    for b in range(NB):
+        # batch 3 arrives unannounced (no prefetch by batch 2): the pipe must upload it itself
+        nxt = h_in[b + 1] if b + 1 < NB and b != 2 else None
+        pipe.run_host(h_in[b], h_out[b], prefetch=nxt)
+        with torch.cuda.stream(pipe.stream):
+            ratios.append(pipe.ratio.clone())      # ordered behind this batch's kernels on the pipe's stream
+    pipe.sync()
+    for b in range(NB):
+        assert np.array_equal(h_out[b], ref[b][0]), b
+        assert np.array_equal(ratios[b].cpu().numpy(), ref[b][1]), b
+    for a in h_in + h_out:
+        pipe.ctx.host_free(a)
+    pipe.close()
 
 
 def test_stream_driver_seam_rule_with_the_real_pipe():

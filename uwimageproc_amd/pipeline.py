@@ -29,7 +29,9 @@ class FramePipe:
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         # share torch's current stream so torch events / synchronize cover our kernels
-        self.ctx = Context(device, stream=torch.cuda.current_stream(self.dev).cuda_stream)
+        self.stream = torch.cuda.current_stream(self.dev)
+        self.ctx = Context(device, stream=self.stream.cuda_stream)
+        self.host = None
         self.F, self.H, self.W = frames, rows, cols
         self.letters, self.w, self.seed = letters.encode(), w, seed
         # the reference's globals videoWidth / videoHeight (main.cpp:238-239); as written they are the
@@ -52,6 +54,11 @@ class FramePipe:
         self.pair_t = (C.c_int32 * frames)(*[i for i in range(frames)])
 
     def close(self):
+        if getattr(self, "host", None) is not None:
+            self.sync()
+            self.host.up_ctx.close()
+            self.host.dn_ctx.close()
+            self.host = None
         if getattr(self, "feats", None):
             self.ctx._l.uwip_features_destroy(self.feats)
             self.feats = None
@@ -104,14 +111,63 @@ class FramePipe:
         shape = (self.F, self.H, self.W, 3)
         return self.ctx.host_alloc(shape), self.ctx.host_alloc(shape)
 
-    def run_host(self, h_in, h_out):
-        """upload -> the four stages -> download, all enqueued on the context's stream; `h_in` / `h_out`
-        come from ``host_buffers``.  Returns without waiting (``ctx.sync()`` drains the stream)."""
-        if getattr(self, "src_dev", None) is None:
-            self.src_dev = torch.empty((self.F, self.H, self.W, 3), dtype=torch.uint8, device=self.dev)
-        self.ctx.h2d_async(self.src_dev, h_in)
-        self.run(self.src_dev)
-        self.ctx.d2h_async(h_out, self.work)
+    def _host_state(self):
+        """Upload and download run on streams of their own, so that batch k+1 arrives and batch k leaves while the kernels
+        of batch k / k+1 run: two source buffers, two result buffers, events for the hand-overs."""
+        if self.host is None:
+            h = type("HostState", (), {})()
+            h.up, h.dn = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
+            h.up_ctx = Context(self.dev.index, stream=h.up.cuda_stream)
+            h.dn_ctx = Context(self.dev.index, stream=h.dn.cuda_stream)
+            h.src = [torch.empty((self.F, self.H, self.W, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
+            h.work = [self.work, torch.empty_like(self.work)]
+            h.uploaded = [torch.cuda.Event() for _ in range(2)]      # src[i] holds its batch
+            h.src_free = [torch.cuda.Event() for _ in range(2)]      # the kernels that read src[i] are done
+            h.downloaded = [torch.cuda.Event() for _ in range(2)]    # work[i] has left for the host
+            h.done = torch.cuda.Event()
+            h.k = 0
+            h.pending = None                                         # host array whose upload into src[k % 2] is in flight
+            self.host = h
+        return self.host
+
+    def _upload(self, h, slot, h_in, first):
+        if not first:
+            h.up.wait_event(h.src_free[slot])
+        h.up_ctx.h2d_async(h.src[slot], h_in)
+        h.uploaded[slot].record(h.up)
+
+    def run_host(self, h_in, h_out, prefetch=None):
+        """upload -> the four stages -> download; `h_in` / `h_out` come from ``host_buffers``.  The copies run on their own
+        streams; with ``prefetch`` (the NEXT batch's input buffer) that batch is uploaded behind this one's dehaze, so a
+        stream of batches never waits for the link.  Returns without waiting (``sync()`` drains all three streams)."""
+        h = self._host_state()
+        k, slot = h.k, h.k % 2
+        if h.pending is not h_in:                                    # nobody prefetched this batch
+            self._upload(h, slot, h_in, first=k < 2)
+        h.pending = None
+        self.stream.wait_event(h.uploaded[slot])
+        if k >= 2:
+            self.stream.wait_event(h.downloaded[slot])               # work[slot] still held batch k-2 on its way out
+        self.work = h.work[slot]
+        self.stage_dehaze_histretch(h.src[slot])
+        h.src_free[slot].record(self.stream)
+        if prefetch is not None:
+            self._upload(h, 1 - slot, prefetch, first=k < 1)
+            h.pending = prefetch
+        self.stage_aclahe()
+        self.stage_overlap()
+        h.done.record(self.stream)
+        h.dn.wait_event(h.done)
+        h.dn_ctx.d2h_async(h_out, self.work)
+        h.downloaded[slot].record(h.dn)
+        h.k = k + 1
+
+    def sync(self):
+        """Drain the pipe's stream and, when the host-buffer front end is in use, its copy streams."""
+        self.ctx.sync()
+        if self.host is not None:
+            self.host.up_ctx.sync()
+            self.host.dn_ctx.sync()
 
     def run(self, src: torch.Tensor):
         self.stage_dehaze_histretch(src)
