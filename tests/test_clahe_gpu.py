@@ -114,7 +114,7 @@ def _mixed_plane(seed, rows, cols):
     return v
 
 
-@pytest.mark.parametrize("shape", [(96, 160), (270, 480), (301, 517)])
+@pytest.mark.parametrize("shape", [(1, 2), (5, 7), (33, 65), (96, 160), (270, 480), (301, 517)])
 def test_sweep_histograms_exact_vs_oracle(ctx, orc, shape):
     """Every one of the 255 output histograms, count for count: the kernel evaluates a clip limit only where its LUTs
     differ from the previous limit's and books the repeats through tail / group counters, so the check is on the
@@ -144,6 +144,21 @@ def test_sweep_histograms_exact_1080p(ctx, orc):
                 c.setClipLimit(aclahe.CLIP_LIMITS[ci])
                 exp = torch.bincount(c.apply(t).flatten().to(torch.int64), minlength=256)
                 assert torch.equal(hist[0, gi, ci].to(torch.int64), exp), (g, ci)
+
+
+def test_sweep_histograms_exact_4k(ctx, orc):
+    """3840x2160 (configs 3 / 5): the same check on one frame; at this size the 16x16 and 32x32 grids hold several cells
+    per block and the 2x2 grid's cells are cut into many row chunks."""
+    t = _dev(_mixed_plane(11, 2160, 3840))
+    _, hist = aclahe.sweep_histograms(ctx, t)
+    assert int(hist.sum(dim=-1).min()) == 2160 * 3840 and int(hist.sum(dim=-1).max()) == 2160 * 3840
+    c = aclahe.CLAHE(ctx)
+    for gi, g in enumerate(aclahe.BLOCK_SIZES):
+        c.setTilesGridSize((g, g))
+        for ci in (0, 3, 16, 17, 30, 34, 50):
+            c.setClipLimit(aclahe.CLIP_LIMITS[ci])
+            exp = torch.bincount(c.apply(t).flatten().to(torch.int64), minlength=256)
+            assert torch.equal(hist[0, gi, ci].to(torch.int64), exp), (g, ci)
 
 
 def test_sweep_1080p_properties(ctx, orc):
