@@ -499,9 +499,6 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
     uint32_t *my_hist = s_hist + (tid % SWEEP_REP) * SWEEP_RSTRIDE;
     const uint8_t *fb = src + (size_t)f * fstride;
     const uint8_t *L = luts + ((size_t)f * SWEEP_NCL + (size_t)cg * SWEEP_GROUP) * tiles * 256;
-    const bool single = (i1 - i0) == 1;
-    uint32_t last_mask = 0xffffffffu;
-    bool copy_at_flush = false;
     for (int it = i0; it < i1; ++it) {
         const CellItem ci = items[it];
         const int tx1 = max(ci.cx - 1, 0), tx2 = min(ci.cx, gx - 1);
@@ -540,12 +537,10 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
 #pragma unroll
         for (int c = 0; c < SWEEP_GROUP; ++c) diffmask |= (s_diff[c] ? 1u : 0u) << c;
         diffmask = __builtin_amdgcn_readfirstlane(diffmask);
-        last_mask = diffmask;
         // nd leading limits with LUTs of their own, then repeats only (the rule); anything else (two limits that still clip
         // but round to one LUT) takes the general path below
         const bool prefix = ((diffmask + 1u) & diffmask) == 0u;
         const int ns = __builtin_popcount(diffmask) - 1;          // limits 0 .. ns-1 go to H, limit ns to T[ns] (block-uniform)
-        if (!prefix && single) copy_at_flush = true;
         // with rep1 the last distinct limit of a prefix cell is the unclipped LUT itself: its output is reused for G
         const bool g_last = g_both && prefix && diffmask != (1u << SWEEP_GROUP) - 1u;
         const bool g_sep = g_any && !g_last;
@@ -629,55 +624,36 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
                 if (g_last) atomicAdd(&s_g[o_last], 65536u);
                 continue;
             }
+            // any other pattern (small tiles: two limits that still clip round to the same integer and give one LUT):
+            // a repeated limit counts the output of the last distinct one again
             uint32_t o = 0;
 #pragma unroll
             for (int c = 0; c < SWEEP_GROUP; ++c) {
-                if (diffmask & (1u << c)) {          // wave-uniform
-                    o = sweep_eval(s_pack[c * 256 + v], xa1, xa, ya1, ya);
-                } else if (single) {
-                    continue;                        // one cell per block: the repeated histogram is copied at flush time
-                }
+                if (diffmask & (1u << c)) o = sweep_eval(s_pack[c * 256 + v], xa1, xa, ya1, ya);     // wave-uniform
                 atomicAdd(&my_hist[(c >> 1) * 256 + o], (c & 1) ? 65536u : 1u);
             }
         }
     }
     __syncthreads();
     uint32_t *out = out_hist + (size_t)f * out_fs + (size_t)cg * SWEEP_GROUP * 256;
-    if (!copy_at_flush) {
-        // H[c] + T[0] + ... + T[min(c, 15)], one thread per grey level walking up the clip limits
-        if (tid < 256) {
-            uint32_t run = 0;
+    // H[c] + T[0] + ... + T[min(c, 15)], one thread per grey level walking up the clip limits
+    if (tid < 256) {
+        uint32_t run = 0;
 #pragma unroll
-            for (int c = 0; c < SWEEP_GROUP; ++c) {
-                const int sh = (c & 1) * 16;
-                if (c < SWEEP_GROUP - 1) run += (s_tail[(c >> 1) * 256 + tid] >> sh) & 0xffffu;
-                uint32_t sum = run;
+        for (int c = 0; c < SWEEP_GROUP; ++c) {
+            const int sh = (c & 1) * 16;
+            if (c < SWEEP_GROUP - 1) run += (s_tail[(c >> 1) * 256 + tid] >> sh) & 0xffffu;
+            uint32_t sum = run;
 #pragma unroll
-                for (int r = 0; r < SWEEP_REP; ++r) sum += (s_hist[r * SWEEP_RSTRIDE + (c >> 1) * 256 + tid] >> sh) & 0xffffu;
-                if (sum) atomicAdd(&out[c * 256 + tid], sum);
-            }
+            for (int r = 0; r < SWEEP_REP; ++r) sum += (s_hist[r * SWEEP_RSTRIDE + (c >> 1) * 256 + tid] >> sh) & 0xffffu;
+            if (sum) atomicAdd(&out[c * 256 + tid], sum);
         }
-    }
-    if (cg == 0 && tid < 256) {
-        const uint32_t g1 = s_hist[(SWEEP_HROWS - 1) * 256 + tid] >> 16;
-        const uint32_t g2 = g1 + (s_hist[SWEEP_RSTRIDE + (SWEEP_HROWS - 1) * 256 + tid] >> 16);
-        if (g1) for (int c = SWEEP_GROUP; c < 2 * SWEEP_GROUP; ++c) atomicAdd(&out[c * 256 + tid], g1);
-        if (g2) for (int c = 2 * SWEEP_GROUP; c < 3 * SWEEP_GROUP; ++c) atomicAdd(&out[c * 256 + tid], g2);
-    }
-    if (!copy_at_flush) return;
-    for (int i = tid; i < SWEEP_GROUP * 256; i += SWEEP_THREADS) {
-        int src = i;
-        if (single) {
-            // clip limit c repeated the outputs of the nearest lower clip limit whose LUTs differed
-            const int c = i >> 8;
-            const uint32_t m = last_mask & ((2u << c) - 1u);
-            src = ((31 - __builtin_clz(m | 1u)) << 8) | (i & 255);
+        if (cg == 0) {
+            const uint32_t g1 = s_hist[(SWEEP_HROWS - 1) * 256 + tid] >> 16;
+            const uint32_t g2 = g1 + (s_hist[SWEEP_RSTRIDE + (SWEEP_HROWS - 1) * 256 + tid] >> 16);
+            if (g1) for (int c = SWEEP_GROUP; c < 2 * SWEEP_GROUP; ++c) atomicAdd(&out[c * 256 + tid], g1);
+            if (g2) for (int c = 2 * SWEEP_GROUP; c < 3 * SWEEP_GROUP; ++c) atomicAdd(&out[c * 256 + tid], g2);
         }
-        uint32_t sum = 0;
-        const int word = ((src >> 9) << 8) | (src & 255), sh = ((src >> 8) & 1) * 16;
-#pragma unroll
-        for (int r = 0; r < SWEEP_REP; ++r) sum += (s_hist[r * SWEEP_RSTRIDE + word] >> sh) & 0xffffu;
-        if (sum) atomicAdd(&out[i], sum);
     }
 }
 
