@@ -472,15 +472,15 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
                                                      int items_per_block,
                                                      uint32_t *__restrict__ out_hist /*[F][51][256]*/,
                                                      size_t out_fs, const uint32_t *__restrict__ tile_max /*[F][tiles]*/,
-                                                     int clip_g1, int clip_g2)
+                                                     ClipList cl)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_sweep[];
     uint32_t *s_pack = s_sweep;                                   // [SWEEP_GROUP][256]
     uint32_t *s_hist = s_sweep + SWEEP_GROUP * 256;               // [SWEEP_REP][SWEEP_HROWS][256], two 16-bit counters per word
     uint32_t *s_tail = s_hist + SWEEP_REP * SWEEP_RSTRIDE;        // [SWEEP_TROWS][256], same packing
-    __shared__ uint32_t s_diff[SWEEP_GROUP];
     const int tid = threadIdx.x;
     const int cg = blockIdx.y, f = blockIdx.z;
+    const int clip_g1 = cl.clip[SWEEP_GROUP - 1], clip_g2 = cl.clip[2 * SWEEP_GROUP - 1];
     const int tiles = gx * gy;
     const uint32_t *tmax = tile_max + (size_t)f * tiles;
     const int i0 = blockIdx.x * items_per_block, i1 = min(nitems, i0 + items_per_block);
@@ -509,9 +509,17 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
         const bool g_any = cg == 0 && rep2, g_both = cg == 0 && rep1;
         uint32_t *s_g = s_hist + (g_both ? 0 : SWEEP_RSTRIDE) + (SWEEP_HROWS - 1) * 256;
         __syncthreads();
+        // nd = how many of the group's 17 limits have LUTs of their own in this cell: limit c repeats limit c-1 once
+        // limit c-1 is at or above the tallest bin of the four tiles (both are then the unclipped LUT), and the limits
+        // grow with c, so the distinct ones come first.  (Block-uniform; small tiles, where two limits that still clip
+        // round to one integer, evaluate such a pair twice: harmless.)
+        int nd = 1;
+        for (int c = 1; c < SWEEP_GROUP; ++c) nd += (uint32_t)cl.clip[cg * SWEEP_GROUP + c - 1] < cellmax ? 1 : 0;
+        const int ns = nd - 1;                                     // limits 0 .. ns-1 go to H, limit ns to T[ns]
         // four grey levels per thread: one dword from each of the four tiles' LUTs, byte-transposed by v_perm into
-        // four packed entries (TL | TR << 8 | BL << 16 | BR << 24) and stored as one 16-byte LDS write
-        for (int idx = tid; idx < SWEEP_GROUP * 64; idx += SWEEP_THREADS) {
+        // four packed entries (TL | TR << 8 | BL << 16 | BR << 24) and stored as one 16-byte LDS write; rows >= nd are
+        // never read
+        for (int idx = tid; idx < nd * 64; idx += SWEEP_THREADS) {
             const int c = idx >> 6, v4 = idx & 63;
             const uint32_t *Lc = reinterpret_cast<const uint32_t *>(L + (size_t)c * tiles * 256);
             const uint32_t a = Lc[((size_t)ty1 * gx + tx1) * 64 + v4];
@@ -524,25 +532,9 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
                 make_uint4(__builtin_amdgcn_perm(u0, t0, 0x05040100u), __builtin_amdgcn_perm(u0, t0, 0x07060302u),
                            __builtin_amdgcn_perm(u1, t1, 0x05040100u), __builtin_amdgcn_perm(u1, t1, 0x07060302u));
         }
-        if (tid < SWEEP_GROUP) s_diff[tid] = tid == 0 ? 1u : 0u;
         __syncthreads();
-        // a clip limit above the tallest bin of all four tiles leaves their LUTs unchanged: when clip limit c has
-        // byte-identical packed LUTs to c-1 in this cell, every pixel's output repeats and need not be recomputed
-        for (int idx = tid + 64; idx < SWEEP_GROUP * 64; idx += SWEEP_THREADS) {
-            const uint4 p = reinterpret_cast<const uint4 *>(s_pack)[idx], q = reinterpret_cast<const uint4 *>(s_pack)[idx - 64];
-            if (((p.x ^ q.x) | (p.y ^ q.y) | (p.z ^ q.z) | (p.w ^ q.w)) != 0u) s_diff[idx >> 6] = 1u;
-        }
-        __syncthreads();
-        uint32_t diffmask = 0;
-#pragma unroll
-        for (int c = 0; c < SWEEP_GROUP; ++c) diffmask |= (s_diff[c] ? 1u : 0u) << c;
-        diffmask = __builtin_amdgcn_readfirstlane(diffmask);
-        // nd leading limits with LUTs of their own, then repeats only (the rule); anything else (two limits that still clip
-        // but round to one LUT) takes the general path below
-        const bool prefix = ((diffmask + 1u) & diffmask) == 0u;
-        const int ns = __builtin_popcount(diffmask) - 1;          // limits 0 .. ns-1 go to H, limit ns to T[ns] (block-uniform)
-        // with rep1 the last distinct limit of a prefix cell is the unclipped LUT itself: its output is reused for G
-        const bool g_last = g_both && prefix && diffmask != (1u << SWEEP_GROUP) - 1u;
+        // with rep1 the last distinct limit is the unclipped LUT itself: its output is reused for G
+        const bool g_last = g_both && nd < SWEEP_GROUP;
         const bool g_sep = g_any && !g_last;
         const int w = ci.x1 - ci.x0;
         const int npix = w * (ci.r1 - ci.r0);
@@ -587,11 +579,11 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
             const float ya = tyf - floorf(tyf), ya1 = 1.0f - ya;
             const uint32_t *pack_v = s_pack + v;
             if (g_sep) atomicAdd(&s_g[sweep_eval(pack_v[0], xa1, xa, ya1, ya)], 65536u);
-            if (diffmask == (1u << SWEEP_GROUP) - 1u) {
+            if (nd == SWEEP_GROUP) {
                 sweep_run<0, SWEEP_GROUP>(pack_v, my_hist, xa1, xa, ya1, ya);      // every clip limit has its own LUTs
                 continue;
             }
-            if (prefix) {
+            {
                 // ns evaluations in straight-line runs of 8 / 4 / 2 / 1 (ns < 16), then the last distinct limit into the tail
                 const uint32_t pk_last = pack_v[ns * 256];
                 if (ns & 8) sweep_run<0, 8>(pack_v, my_hist, xa1, xa, ya1, ya);
@@ -623,14 +615,6 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
                 atomicAdd(&s_tail[(ns >> 1) * 256 + o_last], (ns & 1) ? 65536u : 1u);
                 if (g_last) atomicAdd(&s_g[o_last], 65536u);
                 continue;
-            }
-            // any other pattern (small tiles: two limits that still clip round to the same integer and give one LUT):
-            // a repeated limit counts the output of the last distinct one again
-            uint32_t o = 0;
-#pragma unroll
-            for (int c = 0; c < SWEEP_GROUP; ++c) {
-                if (diffmask & (1u << c)) o = sweep_eval(s_pack[c * 256 + v], xa1, xa, ya1, ya);     // wave-uniform
-                atomicAdd(&my_hist[(c >> 1) * 256 + o], (c & 1) ? 65536u : 1u);
             }
         }
     }
@@ -1093,8 +1077,7 @@ UWIP_API int uwip_aclahe_sweep_hist(uwip_ctx *ctx, const uwip_batch_u8 *src, int
         if (rc) return rc;
         k_clahe_sweep<<<grid, SWEEP_THREADS, sweep_lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.gx,
                                                      g.gy, g.inv_tw, g.inv_th, d_luts, d_items, nitems, ipb,
-                                                     d_out + (size_t)gi * SWEEP_NCL * 256, out_fs, d_tmax,
-                                                     cl.clip[SWEEP_GROUP - 1], cl.clip[2 * SWEEP_GROUP - 1]);
+                                                     d_out + (size_t)gi * SWEEP_NCL * 256, out_fs, d_tmax, cl);
         UWIP_HIP(ctx, hipGetLastError());
     }
     {
