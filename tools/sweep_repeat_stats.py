@@ -6,7 +6,7 @@ import numpy as np
 import torch
 from uwimageproc_amd import aclahe, synth
 from uwimageproc_amd.pipeline import FramePipe
-F, H, W = 8, 1080, 1920
+F, H, W = (2, 2160, 3840) if os.environ.get("STATS_4K") else (8, 1080, 1920)
 pipe = FramePipe(0, F, H, W)
 src = torch.from_numpy(synth.uw_stream(0, F, H, W)).cuda()
 pipe.stage_dehaze(src); pipe.stage_histretch()
