@@ -1217,14 +1217,21 @@ __device__ __forceinline__ void hsv_replace_px(int b, int g, int r, int vnew, co
     or8 = (uint32_t)sat_u8_rne(orr * 255.f);
 }
 
+constexpr int HSV_ROWS_PER_BLOCK = 8;
 // VEC: rows are 4-byte aligned and cols % 4 == 0 -> a thread takes 4 pixels as 3 + 1 dword loads and 3 dword stores
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_hsv_replace_v(const uint8_t *__restrict__ src, size_t sstep, size_t sfs,
                                                       const uint8_t *__restrict__ vnew, size_t vstep, size_t vfs,
                                                       uint8_t *__restrict__ dst, size_t dstep, size_t dfs, int rows,
-                                                      int cols, const int *__restrict__ sdiv, const int *__restrict__ hdiv)
+                                                      int cols, const int *__restrict__ sdiv_g, const int *__restrict__ hdiv_g)
 {
-    const int f = blockIdx.z, y = blockIdx.y;
+    // the two division tables (2 KB) live in LDS: as global gathers they, not the pixels, set the kernel's pace
+    __shared__ int s_tab[512];
+    for (int i = threadIdx.x; i < 256; i += 256) { s_tab[i] = sdiv_g[i]; s_tab[256 + i] = hdiv_g[i]; }
+    __syncthreads();
+    const int *sdiv = s_tab, *hdiv = s_tab + 256;
+    const int f = blockIdx.z;
+    for (int y = blockIdx.y * HSV_ROWS_PER_BLOCK; y < min(rows, (int)(blockIdx.y + 1) * HSV_ROWS_PER_BLOCK); ++y) {
     const uint8_t *s = src + (size_t)f * sfs + (size_t)y * sstep;
     const uint8_t *vn = vnew ? vnew + (size_t)f * vfs + (size_t)y * vstep : nullptr;   // null: keep the pixel's own V
     uint8_t *d = dst + (size_t)f * dfs + (size_t)y * dstep;
@@ -1254,6 +1261,7 @@ __global__ __launch_bounds__(256) void k_hsv_replace_v(const uint8_t *__restrict
             hsv_replace_px(s[3 * x], s[3 * x + 1], s[3 * x + 2], vn ? (int)vn[x] : -1, sdiv, hdiv, ob, og, orr);
             d[3 * x] = (uint8_t)ob; d[3 * x + 1] = (uint8_t)og; d[3 * x + 2] = (uint8_t)orr;
         }
+    }
     }
 }
 
@@ -1287,7 +1295,7 @@ UWIP_API int uwip_hsv_replace_v(uwip_ctx *ctx, const uwip_batch_u8 *bgr, const u
     uwip_kscope ks(ctx, "k_hsv_replace_v");
     auto al4 = [](const uwip_batch_u8 *b) { return ((uintptr_t)b->data | b->step | b->frame_stride) % 4 == 0; };
     const bool vec = bgr->cols % 4 == 0 && al4(bgr) && al4(v_new) && al4(bgr_out);
-    const dim3 grid(uwip_cdiv(vec ? bgr->cols / 4 : bgr->cols, 256), (unsigned)bgr->rows, (unsigned)bgr->frames);
+    const dim3 grid(uwip_cdiv(vec ? bgr->cols / 4 : bgr->cols, 256), (unsigned)uwip_cdiv(bgr->rows, HSV_ROWS_PER_BLOCK), (unsigned)bgr->frames);
     if (vec)
         k_hsv_replace_v<true><<<grid, 256, 0, ctx->stream>>>(
             (const uint8_t *)bgr->data, bgr->step, bgr->frame_stride, (const uint8_t *)v_new->data, v_new->step, v_new->frame_stride,
@@ -1310,7 +1318,7 @@ int uwip_hsv_roundtrip(uwip_ctx *ctx, const uwip_batch_u8 *img)
     if (!tabs) return UWIP_ERR_NOMEM;
     uwip_kscope ks(ctx, "k_hsv_replace_v");
     const bool vec = img->cols % 4 == 0 && ((uintptr_t)img->data | img->step | img->frame_stride) % 4 == 0;
-    const dim3 grid(uwip_cdiv(vec ? img->cols / 4 : img->cols, 256), (unsigned)img->rows, (unsigned)img->frames);
+    const dim3 grid(uwip_cdiv(vec ? img->cols / 4 : img->cols, 256), (unsigned)uwip_cdiv(img->rows, HSV_ROWS_PER_BLOCK), (unsigned)img->frames);
     uint8_t *d = (uint8_t *)img->data;
     if (vec)
         k_hsv_replace_v<true><<<grid, 256, 0, ctx->stream>>>(d, img->step, img->frame_stride, nullptr, 0, 0, d, img->step, img->frame_stride,
