@@ -102,7 +102,7 @@ def test_sweep_vs_oracle(ctx, orc, shape):
 def _mixed_plane(seed, rows, cols):
     """Regions whose tile histograms stop being clipped at different clip limits: 6 grey levels (every limit clips),
     ~20 levels (only the limits of the last group repeat), ~40 levels, white noise (nothing clips beyond the first few
-    limits), a constant patch; region borders do not follow any tile grid."""
+    limits), a constant patch, blown-out (255) areas; region borders do not follow any tile grid."""
     rng = np.random.default_rng(seed)
     v = np.empty((rows, cols), np.uint8)
     xs = [0, cols * 3 // 11, cols * 5 // 11, cols * 8 // 11, cols]
@@ -111,6 +111,8 @@ def _mixed_plane(seed, rows, cols):
     v[:, xs[2]:xs[3]] = rng.integers(0, 256, (rows, xs[3] - xs[2]))
     v[:, xs[3]:xs[4]] = rng.integers(0, 40, (rows, xs[4] - xs[3])) * 6
     v[rows // 3: rows // 2, cols // 4: cols // 2] = 77
+    v[rows // 2: (rows * 3) // 4, cols // 8: (cols * 7) // 8] = 255        # a blown-out band (the sweep's saturated-wave path)
+    v[(rows * 3) // 4:, : cols // 3][::2] = 255                            # ... and one that never fills a whole wave
     return v
 
 
