@@ -49,7 +49,11 @@ def parse():
                     help="skip the 1 GB single-launch measurement of k_clahe_apply (profiling runs: keeps the counter averages of "
                          "that kernel to the step's own launches)")
     ap.add_argument("--no-host-buffers", dest="host_buffers", action="store_false",
-                    help="skip the upload/download-inclusive variant (timed on rank 0 after the main region)")
+                    help="skip the upload/download-inclusive variant (timed on every rank after the main region)")
+    ap.add_argument("--no-4k", dest="fourk", action="store_false",
+                    help="skip the short 3840x2160 leg of the default line (configs 3 / 5: 2 steps + a 2 s paced 4K@60 stream)")
+    ap.add_argument("--no-pin", dest="pin", action="store_false",
+                    help="do not restrict the rank to the CPUs of its GPU's NUMA node")
     a = ap.parse_args()
     big = a.config != "1080p"
     a.rows = a.rows or (2160 if big else 1080)
@@ -82,7 +86,8 @@ def paced_stream(args, dev_index, dev, H, W):
     for w in range(2):                                   # warm-up: workspaces, tables
         h_in[...] = frames[:B]
         pipe.run_host(h_in, h_out)
-        pipe.ctx.sync()
+        pipe.sync()                                      # compute stream AND both copy lanes
+    sentinel_ok = True
     t0 = time.perf_counter() + 0.05
     lat, finish = [], t0
     for k in range(0, n - n % B, B):
@@ -92,17 +97,17 @@ def paced_stream(args, dev_index, dev, H, W):
             time.sleep(arrive_last - now)                # the batch is complete when its last frame has arrived
         for j in range(B):
             h_in[j] = frames[(k + j) % len(frames)]      # the "camera" writes into the pinned ring
-        pipe.run_host(h_in, h_out)
-        pipe.ctx.sync()
+        h_out[-1, -1, -1, :] = (1, 2, 3)                 # no dehazed + stretched frame ends in these bytes twice: proves the D2H landed
+        _, t_out = pipe.run_host(h_in, h_out)
+        pipe.wait_ticket(t_out)                          # the result is in h_out (the download lane has finished)
         finish = time.perf_counter()
+        sentinel_ok = sentinel_ok and tuple(h_out[-1, -1, -1, :]) != (1, 2, 3)
         lat += [finish - (t0 + (k + j) / fps) for j in range(B)]
     done = len(lat)
-    for a in (h_in, h_out):
-        pipe.ctx.host_free(a)
-    pipe.close()
+    pipe.close()                                         # frees the host buffers too
     return {"frames": done, "arrival_fps": fps, "batch": B, "sustained_fps": done / (finish - t0),
             "keeps_up": bool(max(lat) < (B / fps) * 2 + 0.25), "worst_latency_ms": max(lat) * 1e3,
-            "median_latency_ms": float(np.median(lat)) * 1e3,
+            "median_latency_ms": float(np.median(lat)) * 1e3, "result_seen_in_host_buffer": bool(sentinel_ok),
             "note": "latency = result downloaded - frame arrival; a frame waits for its batch to fill, then for upload + pipe + download"}
 
 
@@ -168,16 +173,21 @@ def cpu_baseline(H, W):
     t0 = time.perf_counter()
     one_frame(0, parts)
     single = sum(parts.values())
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    # a bounded sample: one frame per core, at most 32 frames (about as long as the single-thread frame takes)
-    n = min(cores, 32)
+    cores, quota = host_cpus()
+    # a bounded sample: one frame per core the job may really use (the affinity mask, cut to the cgroup's CPU quota
+    # when there is one), at most 256 and at most what half of the free memory holds at ~0.7 GB per frame in flight
+    try:
+        free_gb = os.sysconf("SC_AVPHYS_PAGES") * os.sysconf("SC_PAGE_SIZE") / 2**30
+    except (ValueError, OSError):
+        free_gb = 64.0
+    n = max(1, min(cores, int(np.ceil(quota)) if quota else cores, 256, int(free_gb / 2 / 0.7)))
     t1 = time.perf_counter()
     with ThreadPoolExecutor(max_workers=n) as ex:
         list(ex.map(one_frame, range(1, n + 1)))
     wall = time.perf_counter() - t1
-    return {"value": n / wall, "unit": "frames/s", "cores": n, "kind": "port",
-            "sample": f"{n} frames of {W}x{H}, one per host thread ({cores} cores visible), whole pipe in C ({build}); "
-                      f"single thread: 1 frame",
+    return {"value": n / wall, "unit": "frames/s", "cores": n, "cores_visible": cores, "cgroup_cpu_quota": quota, "kind": "port",
+            "sample": f"{n} frames of {W}x{H}, one per host thread ({cores} CPUs in the affinity mask, cgroup quota "
+                      f"{quota if quota else 'none'}), whole pipe in C ({build}); single thread: 1 frame",
             "single_thread": {"value": 1.0 / single, "unit": "frames/s", "cores": 1, "seconds_per_frame": single, "parts": parts},
             "all_cores_wall_s": wall, "total_cpu_baseline_s": time.perf_counter() - t0}
 
@@ -386,18 +396,15 @@ def free_port():
 
 
 def self_launch(args):
-    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE this
-    process touches the GPU, relay rank 0's JSON line, and exit with the worst return code.  With fewer
-    visible devices than ranks (a 1-GPU box) the ranks share devices and rendezvous over gloo -- a plumbing
-    rehearsal, flagged "ranks_share_gpu" in the line."""
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) from a parent that never
+    makes a GPU runtime call, relay rank 0's JSON line, and exit with the worst return code.  A rank that finds fewer
+    visible devices than ranks (a 1-GPU box) shares devices and rendezvous over gloo -- a plumbing rehearsal, flagged
+    "ranks_share_gpu" in the line."""
     import subprocess
     n = args.gpus
-    ndev = torch.cuda.device_count()          # does not initialise the GPU on this image
     env = dict(os.environ)
-    env.update({"WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
+    env.update({"WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(free_port()),
                 "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
-    if ndev < n:
-        env["UWIP_BENCH_BACKEND"] = "gloo"
     procs = []
     for r in range(n):
         e = dict(env)
@@ -413,6 +420,166 @@ def self_launch(args):
     sys.exit(rc)
 
 
+class Rig:
+    """S independent sub-batch pipes of one rank, each on its own HIP stream and driven by its own host thread (frames are
+    independent units: the HBM-bound dehaze passes of one sub-batch overlap the VALU-bound sweep and the host-side ACLAHE
+    parameter choice of another), plus the rank's one copier (upload lane + download lane) for the host-buffer mode."""
+
+    def __init__(self, dev_index, dev, F, H, W, S, seed0):
+        from uwimageproc_amd import Copier
+        from uwimageproc_amd.pipeline import FramePipe
+        assert F % S == 0, "--frames must be divisible by --streams"
+        self.F, self.H, self.W, self.S, self.Fs = F, H, W, S, F // S
+        Fs = self.Fs
+        # one sub-batch worth of DISTINCT consecutive frames of the synthetic stream (seed = 1234 + index, SURVEY 8d), the
+        # same ones for every sub-batch: every launch works on Fs different images
+        distinct = min(Fs, 64)
+        base = synth_frames(distinct, H, W, seed0)
+        one = np.concatenate([base] * ((Fs + distinct - 1) // distinct), axis=0)[:Fs]
+        self.src = torch.from_numpy(np.concatenate([one] * S, axis=0)).to(dev)
+        torch.cuda.synchronize()
+        self.copier = Copier(dev_index)
+        self.pipes = []
+        for i in range(S):
+            with torch.cuda.stream(torch.cuda.Stream(dev)):
+                self.pipes.append(FramePipe(dev_index, Fs, H, W, copier=self.copier))
+        self.parts = [self.src[i * Fs:(i + 1) * Fs] for i in range(S)]
+        self.bufs = None
+
+    def on_all(self, fn):
+        """fn(i) for every sub-batch, each on its own host thread (a uwip context is single-threaded; one per thread)"""
+        import threading
+        if self.S == 1:
+            fn(0)
+            return
+        th = [threading.Thread(target=fn, args=(i,)) for i in range(1, self.S)]
+        for t in th:
+            t.start()
+        fn(0)
+        for t in th:
+            t.join()
+
+    def run_steps(self, k):
+        """k steps: every sub-batch thread runs its k passes back to back (no per-step rendezvous between the host threads)"""
+        def loop(i):
+            for _ in range(k):
+                self.pipes[i].run(self.parts[i])
+        self.on_all(loop)
+
+    def host_prepare(self):
+        self.bufs = [p.host_buffers() for p in self.pipes]
+        for i in range(self.S):
+            self.bufs[i][0][...] = self.parts[i].cpu().numpy()
+        torch.cuda.synchronize()
+
+    def run_steps_host(self, k):
+        """the same k steps with every frame uploaded from and downloaded to page-locked host memory"""
+        def loop(i):
+            p, (hi, ho) = self.pipes[i], self.bufs[i]
+            for _ in range(k):
+                p.run_host(hi, ho, prefetch=hi)
+        self.on_all(loop)
+
+    def drain(self):
+        for p in self.pipes:
+            p.sync()
+        torch.cuda.synchronize()
+
+    def close(self):
+        for p in self.pipes:
+            p.close()
+        self.copier.close()
+        self.pipes, self.parts, self.src, self.bufs = [], [], None, None
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+
+
+def timed(rig, world, steps, warmup, host):
+    """warm-up, then EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; max over ranks"""
+    from uwimageproc_amd import sharding
+    run = rig.run_steps_host if host else rig.run_steps
+    run(warmup)
+    rig.drain()
+    barrier(world)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    rig.drain()                                   # compute streams and, in host mode, the last downloads
+    barrier(world)
+    torch.cuda.synchronize()
+    return sharding.max_over_ranks(time.perf_counter() - t0)
+
+
+def host_leg(rig, world, steps):
+    """Host-buffer variant: the reference's own timed region brackets upload ... download (histretch.cpp:165,174-175,
+    212-213,257-261).  Every step copies its frames from page-locked host memory to HBM and the processed frames back
+    inside the timed region (the rank's copier: one upload and one download lane, batch k+1 arrives and batch k leaves
+    under the kernels).  Runs on every rank; the time is the max over ranks."""
+    from uwimageproc_amd import sharding
+    rig.host_prepare()
+    dt_h = timed(rig, world, steps, 1, host=True)
+    same = all(np.array_equal(rig.bufs[i][1], rig.pipes[i].work.cpu().numpy()) for i in range(rig.S))
+    same = sharding.max_over_ranks(0.0 if same else 1.0) == 0.0
+    F = rig.F
+    return {"value": world * F * steps / dt_h, "unit": "frames/s", "ms_per_step": dt_h / steps * 1e3,
+            "gbytes_per_s_each_way_per_gpu": F * rig.H * rig.W * 3 * steps / dt_h / 1e9, "downloaded_equals_device": bool(same),
+            "ranks": world,
+            "note": "the same steps on every rank with page-locked host -> HBM and HBM -> page-locked host copies of every frame "
+                    "inside the timed region (uwip_copier: one upload and one download lane per rank, requests served in order "
+                    "at the full link rate, hand-overs waited for on the host: no device-side cross-stream barrier)"}
+
+
+def fourk_leg(args, dev_index, dev, rank, world):
+    """BASELINE configs 3 / 5 inside the default line: the same pipe on 3840x2160 frames (64 per GPU and step), 2 steps
+    HBM-resident and 2 steps through host buffers, then config 5's paced 4K@60 stream (a short one: 2 s) on every rank."""
+    from uwimageproc_amd import sharding
+    H, W, F, S = 2160, 3840, 64, max(1, args.streams)
+    rig = Rig(dev_index, dev, F, H, W, S, 4321 + 1000 * rank)
+    steps = 2
+    dt = timed(rig, world, steps, 1, host=False)
+    out = {"workload": f"full pipe on {W}x{H} uchar3 frames, {F} per GPU and step", "steps": steps,
+           "value": world * F * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3}
+    if args.host_buffers:
+        h = host_leg(rig, world, steps)
+        out["value_end_to_end"] = h["value"]
+        out["host_buffers"] = h
+    rig.close()
+    del rig
+    torch.cuda.empty_cache()
+    import copy
+    a2 = copy.copy(args)
+    a2.paced_frames = min(args.paced_frames, 120)
+    paced = paced_stream(a2, dev_index, dev, H, W)
+    paced["worst_latency_ms"] = sharding.max_over_ranks(paced["worst_latency_ms"])
+    paced["sustained_fps_min_over_ranks"] = -sharding.max_over_ranks(-paced["sustained_fps"])
+    paced["streams"] = f"one 60 fps camera per rank x {world}"
+    out["paced_stream"] = paced
+    return out
+
+
+def host_cpus():
+    """(CPUs in the affinity mask, cgroup CPU quota or None)"""
+    vis = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    return vis, quota
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -420,11 +587,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback)"
-    # one process per GPU; UWIP_BENCH_BACKEND=gloo lets several ranks share one GPU (plumbing smoke test only)
-    backend = os.environ.get("UWIP_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    ndev = torch.cuda.device_count()                         # a count only: no context is created by it
+    # one process per GPU; with fewer devices than ranks (or UWIP_BENCH_BACKEND=gloo) several ranks share a GPU
+    backend = os.environ.get("UWIP_BENCH_BACKEND", "nccl" if ndev >= local_world else "gloo")
     dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    # placement first: before the first GPU call and before any thread of this rank exists, restrict the process to the
+    # CPUs next to its GPU (the sub-batch threads, the copier lanes, the host pool and the first-touched pinned
+    # buffers all follow); the CPU baseline below widens the mask again for its own threads
+    all_cpus = sorted(os.sched_getaffinity(0))
+    placement = {"pinned": False, "error": "--no-pin"}
+    if args.pin:
+        from uwimageproc_amd import affinity
+        placement = affinity.pin_rank_to_gpu(dev_index, ranks_on_node=min(local_world, max(ndev, 1)), local_rank=dev_index)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (there is no CPU fallback)"
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     if world > 1:
@@ -434,129 +610,47 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    from uwimageproc_amd import synth
-    from uwimageproc_amd.pipeline import FramePipe
-
     F, H, W = args.frames, args.rows, args.cols
     S = max(1, args.streams)
-    assert F % S == 0, "--frames must be divisible by --streams"
-    Fs = F // S
-    # one sub-batch worth of DISTINCT consecutive frames of the synthetic stream (seed = 1234 + index), the
-    # same ones for every sub-batch: every launch works on Fs different images
-    distinct = min(Fs, 64)
-    base = synth_frames(distinct, H, W, 1234 + 1000 * rank)                  # a different scene per rank, same size
-    reps = (Fs + distinct - 1) // distinct
-    one = np.concatenate([base] * reps, axis=0)[:Fs]
-    src = torch.from_numpy(np.concatenate([one] * S, axis=0)).to(dev)
-    del one, base
-    torch.cuda.synchronize()
-    # S independent pipes, each on its own HIP stream and driven by its own host thread: frames are independent
-    # units, so the HBM-bound dehaze passes of one half-batch overlap the LDS-bound sweep and the host-side
-    # ACLAHE parameter choice of the other
-    streams = [torch.cuda.Stream(dev) for _ in range(S)]
-    pipes = []
-    for i in range(S):
-        with torch.cuda.stream(streams[i]):
-            pipes.append(FramePipe(dev_index, Fs, H, W))
-    pipe = pipes[0]
-    parts = [src[i * Fs:(i + 1) * Fs] for i in range(S)]
+    rig = Rig(dev_index, dev, F, H, W, S, 1234 + 1000 * rank)        # a different scene per rank, same size
+    pipe = rig.pipes[0]
 
-    import threading
+    dt = timed(rig, world, args.steps, args.warmup, host=False)
 
-    def on_all_pipes(fn):
-        """fn(i) for every sub-batch, each on its own host thread (a uwip context is single-threaded; one per thread)"""
-        if S == 1:
-            fn(0)
-            return
-        th = [threading.Thread(target=fn, args=(i,)) for i in range(1, S)]
-        for t in th:
-            t.start()
-        fn(0)
-        for t in th:
-            t.join()
-
-    def run_steps(k):
-        """k steps: every sub-batch thread runs its k passes back to back (no per-step rendezvous between the host
-        threads, so the sub-batches drift apart and one's sweep overlaps another's guided filter)."""
-        def loop(i):
-            for _ in range(k):
-                pipes[i].run(parts[i])
-        on_all_pipes(loop)
-
-    def barrier():
-        if world > 1:
-            import torch.distributed as dist
-            dist.barrier()
-
-    run_steps(args.warmup)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    from uwimageproc_amd import sharding
-    dt = sharding.max_over_ranks(dt)          # the slowest rank defines the step time
-
-    # Host-buffer variant (reported next to `value`, never as `value`): the reference's own timed region brackets
-    # upload ... download (histretch.cpp:165,174-175,212-213,257-261).  Every step copies its frames from page-locked
-    # host memory to HBM and the processed frames back, with the library's own staging buffers and
-    # hipMemcpyAsync on each sub-batch's stream (uwip_host_alloc / uwip_memcpy_*_async); the copies of one
-    # sub-batch overlap the kernels of the other three.
-    host = None
-    if args.host_buffers and world == 1:
-        bufs = [pipes[i].host_buffers() for i in range(S)]
-        for i in range(S):
-            bufs[i][0][...] = parts[i].cpu().numpy()
-        torch.cuda.synchronize()
-
-        def steps_host(k):
-            def loop(i):
-                for _ in range(k):
-                    pipes[i].run_host(bufs[i][0], bufs[i][1], prefetch=bufs[i][0])
-            on_all_pipes(loop)
-
-        steps_host(1)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        steps_host(args.steps)
-        torch.cuda.synchronize()
-        dt_h = time.perf_counter() - t1
-        same = all(np.array_equal(bufs[i][1], pipes[i].work.cpu().numpy()) for i in range(S))
-        host = {"value": F * args.steps / dt_h, "unit": "frames/s", "ms_per_step": dt_h / args.steps * 1e3,
-                "gbytes_per_s_each_way": F * H * W * 3 * args.steps / dt_h / 1e9, "downloaded_equals_device": bool(same),
-                "note": "same steps on this rank with page-locked host -> HBM and HBM -> page-locked host copies of every "
-                        "frame inside the timed region (library staging buffers; hipMemcpyAsync on an upload and a download "
-                        "stream per sub-batch, two source and two result buffers: batch k+1 arrives and batch k leaves "
-                        "under the kernels)"}
-        for i in range(S):
-            for a in bufs[i]:
-                pipes[i].ctx.host_free(a)
-        del bufs
+    host = host_leg(rig, world, args.steps) if args.host_buffers else None
 
     # per-kernel timing pass (HIP events on the launch stream, inside libuwip)
     roof = None
     kernels = {}
+    stages = pipe.stages()
     if rank == 0:
-        roof, kernels = roofline_report(args, pipe, parts[0], dev, F, Fs, H, W)
+        roof, kernels = roofline_report(args, pipe, rig.parts[0], dev, F, rig.Fs, H, W)
+    barrier(world)
 
+    rig.close()
+    del rig, pipe
+    torch.cuda.empty_cache()
     paced = None
-    if args.config == "4k-paced" and world == 1:
-        for pp in pipes:
-            pp.close()
+    if args.config == "4k-paced":
         paced = paced_stream(args, dev_index, dev, H, W)
+    fourk = None
+    if args.config == "1080p" and args.fourk and (H, W) == (1080, 1920):
+        try:
+            fourk = fourk_leg(args, dev_index, dev, rank, world)
+        except Exception as ex:                               # a side measurement never loses the line (all ranks take part)
+            fourk = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
+    barrier(world)
     if rank == 0:
         cpu = None
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline:
+            os.sched_setaffinity(0, all_cpus)                 # the CPU baseline may use every core the job was given
             cpu = cpu_baseline(H, W)
         total_frames = world * F * args.steps
         line = {
             "metric": "frames/sec whole-node, 1080p full pipe (dehaze+stretch+CLAHE+overlap)" if (H, W) == (1080, 1920)
                       else f"frames/sec whole-node, {W}x{H} full pipe (dehaze+stretch+CLAHE+overlap)",
             "value": total_frames / dt,
+            "value_end_to_end": None if host is None else host["value"],
             "unit": "frames/s",
             "n_gpus": world,
             "ranks_share_gpu": bool(world > max(ndev, 1)),
@@ -570,19 +664,23 @@ def main():
             "data": "synthetic",
             "config": {"name": args.config,
                        "workload": f"full pipe bgdehaze->histretch->aclahe->videostrip-overlap on {W}x{H} uchar3 frames",
-                       "frames_per_gpu_per_step": F, "streams_per_gpu": S, "stages": pipe.stages(),
-                       "parallelism": f"frame-batch x{world}"},
+                       "frames_per_gpu_per_step": F, "streams_per_gpu": S, "stages": stages,
+                       "parallelism": f"frame-batch x{world}", "rank0_placement": placement},
+            "value_note": "value: frames resident in HBM when the timed region starts (the contract's definition); "
+                          "value_end_to_end: every frame uploaded from and downloaded to page-locked host memory inside the "
+                          "timed region (the reference's own timed region, histretch.cpp:165-216), same steps, max over ranks",
             "roofline": roof,
             "cpu_baseline": cpu,
             "host_buffers": host,
             "paced_stream": paced,
+            "config_4k": fourk,
             "kernels": kernels,
         }
         print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist
         sys.stdout.flush()
-        dist.barrier()                      # rank 0 may still have been printing its per-kernel report
+        dist.barrier()                      # rank 0 may still have been busy with the CPU baseline
         dist.destroy_process_group()
 
 

@@ -24,17 +24,19 @@ struct Reader {
     {
         if (!imgio::read_file(path, buf) || buf.size() < 12) return false;
         if (std::memcmp(&buf[0], "RIFF", 4) != 0 || std::memcmp(&buf[8], "AVI ", 4) != 0) return false;
-        walk(12, buf.size());
+        walk(12, buf.size(), 0);
         return !frames.empty();
     }
-    void walk(size_t pos, size_t end)
+    // LIST chunks nest at most three deep in a real AVI (RIFF > movi > rec); a crafted file may not recurse further
+    static constexpr int MAX_DEPTH = 8;
+    void walk(size_t pos, size_t end, int depth)
     {
         while (pos + 8 <= end) {
             const uint32_t len = le32(&buf[pos + 4]);
             const size_t body = pos + 8, next = body + len + (len & 1);
-            if (body + len > buf.size()) break;
+            if (body + len > end) break;               // a child may not overrun its parent
             if (std::memcmp(&buf[pos], "LIST", 4) == 0 && len >= 4) {
-                walk(body + 4, body + len);
+                if (depth < MAX_DEPTH) walk(body + 4, body + len, depth + 1);
             } else if (std::memcmp(&buf[pos], "avih", 4) == 0 && len >= 40) {
                 const uint32_t us = le32(&buf[body]);
                 if (us) fps = 1e6 / (double)us;

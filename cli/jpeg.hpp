@@ -23,52 +23,55 @@ static const uint8_t ZIGZAG[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 2
 // ---- the slow-but-accurate integer DCT pair (CONST_BITS 13, PASS1_BITS 2) ------------------------------------------
 enum { CB = 13, P1 = 2 };
 static inline int32_t descale(int32_t x, int n) { return (x + (1 << (n - 1))) >> n; }
+static inline int64_t descale64(int64_t x, int n) { return (x + ((int64_t)1 << (n - 1))) >> n; }
 enum : int32_t { F0298 = 2446, F0390 = 3196, F0541 = 4433, F0765 = 6270, F0899 = 7373, F1175 = 9633, F1501 = 12299,
                  F1847 = 15137, F1961 = 16069, F2053 = 16819, F2562 = 20995, F3072 = 25172 };
 
-// coef: 64 dequantised coefficients in natural order; out: 64 samples 0..255
+// coef: 64 dequantised coefficients in natural order (|coef| <= 2^20, the decoder clamps: a valid stream stays far
+// below); out: 64 samples 0..255.  64-bit temporaries: the same values as libjpeg's 32-bit ones on a valid stream, and no
+// signed overflow on a corrupt one.
 static inline void idct_islow(const int32_t *coef, uint8_t *out, int ostride)
 {
-    int32_t ws[64];
+    int64_t ws[64];
     for (int c = 0; c < 8; ++c) {
         const int32_t *in = coef + c;
-        int32_t z2 = in[16], z3 = in[48];
-        int32_t z1 = (z2 + z3) * F0541;
-        int32_t tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+        int64_t z2 = in[16], z3 = in[48];
+        int64_t z1 = (z2 + z3) * F0541;
+        int64_t tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
         z2 = in[0]; z3 = in[32];
-        int32_t tmp0 = (z2 + z3) * (1 << CB), tmp1 = (z2 - z3) * (1 << CB);
-        const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        int64_t tmp0 = (z2 + z3) * (1 << CB), tmp1 = (z2 - z3) * (1 << CB);
+        const int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = in[56]; tmp1 = in[40]; tmp2 = in[24]; tmp3 = in[8];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-        int32_t z4 = tmp1 + tmp3;
-        const int32_t z5 = (z3 + z4) * F1175;
+        int64_t z4 = tmp1 + tmp3;
+        const int64_t z5 = (z3 + z4) * F1175;
         tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
         z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
         z3 += z5; z4 += z5;
         tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-        int32_t *w = ws + c;
-        w[0] = descale(tmp10 + tmp3, CB - P1);  w[56] = descale(tmp10 - tmp3, CB - P1);
-        w[8] = descale(tmp11 + tmp2, CB - P1);  w[48] = descale(tmp11 - tmp2, CB - P1);
-        w[16] = descale(tmp12 + tmp1, CB - P1); w[40] = descale(tmp12 - tmp1, CB - P1);
-        w[24] = descale(tmp13 + tmp0, CB - P1); w[32] = descale(tmp13 - tmp0, CB - P1);
+        int64_t *w = ws + c;
+        w[0] = descale64(tmp10 + tmp3, CB - P1);  w[56] = descale64(tmp10 - tmp3, CB - P1);
+        w[8] = descale64(tmp11 + tmp2, CB - P1);  w[48] = descale64(tmp11 - tmp2, CB - P1);
+        w[16] = descale64(tmp12 + tmp1, CB - P1); w[40] = descale64(tmp12 - tmp1, CB - P1);
+        w[24] = descale64(tmp13 + tmp0, CB - P1); w[32] = descale64(tmp13 - tmp0, CB - P1);
     }
     for (int r = 0; r < 8; ++r) {
-        const int32_t *w = ws + r * 8;
-        int32_t z2 = w[2], z3 = w[6];
-        int32_t z1 = (z2 + z3) * F0541;
-        int32_t tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
-        int32_t tmp0 = (w[0] + w[4]) * (1 << CB), tmp1 = (w[0] - w[4]) * (1 << CB);
-        const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+        const int64_t *w = ws + r * 8;
+        int64_t z2 = w[2], z3 = w[6];
+        int64_t z1 = (z2 + z3) * F0541;
+        int64_t tmp2 = z1 + z3 * (-F1847), tmp3 = z1 + z2 * F0765;
+        int64_t tmp0 = (w[0] + w[4]) * (1 << CB), tmp1 = (w[0] - w[4]) * (1 << CB);
+        const int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
         tmp0 = w[7]; tmp1 = w[5]; tmp2 = w[3]; tmp3 = w[1];
         z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-        int32_t z4 = tmp1 + tmp3;
-        const int32_t z5 = (z3 + z4) * F1175;
+        int64_t z4 = tmp1 + tmp3;
+        const int64_t z5 = (z3 + z4) * F1175;
         tmp0 *= F0298; tmp1 *= F2053; tmp2 *= F3072; tmp3 *= F1501;
         z1 *= -F0899; z2 *= -F2562; z3 *= -F1961; z4 *= -F0390;
         z3 += z5; z4 += z5;
         tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-        auto put = [&](int i, int32_t v) {
-            const int32_t s = descale(v, CB + P1 + 3) + 128;
+        auto put = [&](int i, int64_t v) {
+            const int64_t s = descale64(v, CB + P1 + 3) + 128;
             out[r * ostride + i] = (uint8_t)(s < 0 ? 0 : (s > 255 ? 255 : s));
         };
         put(0, tmp10 + tmp3); put(7, tmp10 - tmp3); put(1, tmp11 + tmp2); put(6, tmp11 - tmp2);
@@ -125,18 +128,21 @@ struct HuffTable {
     uint16_t ecode[256];
     uint8_t esize[256];
     bool present = false;
-    void build()
+    // false: the counts do not describe a prefix code (over-subscribed lengths, libjpeg's JERR_BAD_HUFF_TABLE)
+    bool build()
     {
+        present = false;
         uint8_t huffsize[257];
         uint16_t huffcode[257];
         int p = 0;
-        for (int l = 1; l <= 16; ++l) for (int i = 0; i < bits[l]; ++i) huffsize[p++] = (uint8_t)l;
+        for (int l = 1; l <= 16; ++l) for (int i = 0; i < bits[l]; ++i) { if (p >= 256) return false; huffsize[p++] = (uint8_t)l; }
         huffsize[p] = 0;
         const int n = p;
         int code = 0, si = huffsize[0];
         p = 0;
         while (huffsize[p]) {
             while (huffsize[p] == si) huffcode[p++] = (uint16_t)code++;
+            if (code >= (1 << si)) return false;     // more codes of length si than the prefix tree has room for
             code <<= 1; si++;
         }
         p = 0;
@@ -155,6 +161,7 @@ struct HuffTable {
         std::memset(esize, 0, sizeof esize);
         for (int i = 0; i < n; ++i) { ecode[vals[i]] = huffcode[i]; esize[vals[i]] = huffsize[i]; }
         present = true;
+        return true;
     }
 };
 
@@ -197,6 +204,7 @@ static inline int huff_decode(BitReader &br, const HuffTable &h)
     const int idx = h.valptr[l] + (code >> (16 - l));
     return (idx >= 0 && idx < 256) ? h.vals[idx] : -1;
 }
+static inline int32_t clamp_coef(int64_t v) { return (int32_t)(v > (1 << 20) ? (1 << 20) : (v < -(1 << 20) ? -(1 << 20) : v)); }
 static inline int extend(int v, int t) { return v < (1 << (t - 1)) ? v - (1 << t) + 1 : v; }
 
 struct Component {
@@ -249,13 +257,14 @@ inline bool decode(const uint8_t *buf, size_t len, int &rows, int &cols, int &ch
                 if (n > 256 || s + n > e) return false;
                 std::memcpy(t.vals, s, n);
                 s += n;
-                t.build();
+                if (!t.build()) return false;
             }
         } else if (m == 0xC0 || m == 0xC1) {
-            if (s[0] != 8) return false;
+            if (L < 8 || s[0] != 8) return false;
             H = (s[1] << 8) | s[2]; W = (s[3] << 8) | s[4];
             const int n = s[5];
-            if ((n != 1 && n != 3) || W <= 0 || H <= 0) return false;
+            if ((n != 1 && n != 3) || W <= 0 || H <= 0 || L < (size_t)(8 + 3 * n)) return false;
+            if (have_sof) return false;             // one frame per file
             comp.resize(n);
             for (int i = 0; i < n; ++i) {
                 comp[i].id = s[6 + 3 * i]; comp[i].h = s[7 + 3 * i] >> 4; comp[i].v = s[7 + 3 * i] & 15; comp[i].tq = s[8 + 3 * i] & 3;
@@ -266,13 +275,15 @@ inline bool decode(const uint8_t *buf, size_t len, int &rows, int &cols, int &ch
         } else if (m == 0xC2 || (m >= 0xC5 && m <= 0xCF && m != 0xC8 && m != 0xCC)) {
             return false;                   // progressive / lossless / arithmetic: not the baseline this decoder reads
         } else if (m == 0xDD) {
+            if (L < 4) return false;
             restart = (s[0] << 8) | s[1];
         } else if (m == 0xDA) {
-            if (!have_sof) return false;
+            if (!have_sof || L < 3) return false;
             const int ns = s[0];
-            if (ns != (int)comp.size()) return false;       // one interleaved scan (what baseline encoders write)
+            if (ns != (int)comp.size() || L < (size_t)(6 + 2 * ns)) return false;       // one interleaved scan (what baseline encoders write)
             for (int i = 0; i < ns; ++i)
                 for (auto &c : comp) if (c.id == s[1 + 2 * i]) { c.td = s[2 + 2 * i] >> 4; c.ta = s[2 + 2 * i] & 15; }
+            for (auto &c : comp) if (c.td > 3 || c.ta > 3) return false;
             pos += L;
             // ---- the entropy-coded segment
             const int mcux = (W + 8 * hmax - 1) / (8 * hmax), mcuy = (H + 8 * vmax - 1) / (8 * vmax);
@@ -304,7 +315,8 @@ inline bool decode(const uint8_t *buf, size_t len, int &rows, int &cols, int &ch
                                 if (t < 0 || t > 11) return false;
                                 const int diff = t ? extend(br.get(t), t) : 0;
                                 c.pred += diff;
-                                blk[0] = c.pred * qt[c.tq][0];
+                                if (c.pred > 32767 || c.pred < -32768) return false;     // a valid DC stays within 12 bits
+                                blk[0] = clamp_coef((int64_t)c.pred * qt[c.tq][0]);
                                 for (int k = 1; k < 64;) {
                                     const int rs = huff_decode(br, ac[c.ta]);
                                     if (rs < 0) return false;
@@ -313,7 +325,7 @@ inline bool decode(const uint8_t *buf, size_t len, int &rows, int &cols, int &ch
                                     k += r;
                                     if (k > 63) return false;
                                     const int z = ZIGZAG[k];
-                                    blk[z] = extend(br.get(sz), sz) * qt[c.tq][z];
+                                    blk[z] = clamp_coef((int64_t)extend(br.get(sz), sz) * qt[c.tq][z]);
                                     ++k;
                                 }
                                 const int X = (mx * c.h + bx) * 8, Y = (my * c.v + by) * 8, stride = c.wblocks * 8;

@@ -98,6 +98,29 @@ int uwip_host_free(uwip_ctx *ctx, void *h_ptr);
 int uwip_memcpy_h2d_async(uwip_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int uwip_memcpy_d2h_async(uwip_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 
+/* Copy engine for a stream of frame batches (the double-buffered form of
+ * GpuMat::upload ... download around the timed region, histretch.cpp:165-216;
+ * SURVEY.md section 7 "PCIe feed").  One per device / rank: an upload lane and a
+ * download lane, each a host thread with a stream of its own that serves its
+ * requests first in, first out.  A request with `after` != NULL starts once
+ * everything queued on that context's stream AT THE TIME OF THE CALL has
+ * finished (the lane waits for it on the host, so a copy is only handed to the
+ * DMA engine when it can run: no hardware queue ever holds a barrier packet
+ * that waits for a copy or for another stream -- with more streams than the
+ * runtime has hardware queues such packets stall unrelated kernels).  A ticket
+ * names the request: uwip_copier_wait blocks the calling host thread until
+ * that copy has completed (ticket 0: returns at once), after which the host
+ * buffer may be reused (upload) or read (download), and the device buffer may
+ * be read by kernels queued from then on.  Requests may come from any thread. */
+typedef struct uwip_copier uwip_copier;
+int uwip_copier_create(int device, uwip_copier **out);
+int uwip_copier_destroy(uwip_copier *c);                 /* drains both lanes first */
+int uwip_copier_upload(uwip_copier *c, uwip_ctx *after, void *d_dst, const void *h_src, size_t bytes, uint64_t *ticket);
+int uwip_copier_download(uwip_copier *c, uwip_ctx *after, void *h_dst, const void *d_src, size_t bytes, uint64_t *ticket);
+int uwip_copier_wait(uwip_copier *c, uint64_t ticket);
+int uwip_copier_query(uwip_copier *c, uint64_t ticket, int *done);
+const char *uwip_copier_last_error(const uwip_copier *c);
+
 /* Per-kernel hipEvent timing on the context's stream (replaces the
  * getTickCount stopwatch, histretch.cpp:165,257-261).  Enabling it brackets
  * every kernel launch with events; totals are read back per kernel name. */

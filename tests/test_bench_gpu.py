@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 def _run(extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--frames", "8", "--streams", "2",
-           "--rows", "270", "--cols", "480", "--no-cpu-baseline", "--no-matcher-bench"] + extra
+           "--rows", "270", "--cols", "480", "--no-matcher-bench"] + extra
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
@@ -23,9 +23,14 @@ def _run(extra):
 
 
 def test_bench_self_launches_two_ranks():
-    one = _run(["--gpus", "1"])
-    two = _run(["--gpus", "2", "--no-host-buffers"])
+    one = _run(["--gpus", "1", "--no-cpu-baseline"])
+    two = _run(["--gpus", "2"])
     assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    # the N > 1 line is a complete record: the host-buffer leg ran on every rank (max over ranks) and rank 0 timed the CPU baseline
+    assert two["host_buffers"] is not None and two["host_buffers"]["ranks"] == 2 and two["host_buffers"]["downloaded_equals_device"]
+    assert two["value_end_to_end"] == two["host_buffers"]["value"] > 0
+    assert two["cpu_baseline"] is not None and two["cpu_baseline"]["value"] > 0 and two["cpu_baseline"]["cores"] >= 1
+    assert "rank0_placement" in two["config"]
     assert two["config"]["frames_per_gpu_per_step"] == 8
     # whole-job frames per step doubles with the ranks (weak scaling): value * ms_per_step = frames per step
     f1 = one["value"] * one["ms_per_step"] / 1e3

@@ -279,3 +279,81 @@ def test_bgdehaze_cli_on_the_references_photograph(tmp_path):
     assert got.shape == ref.shape
     assert np.abs(got - ref).mean() < 7.5
     assert min(np.corrcoef(got[:, :, c].ravel(), ref[:, :, c].ravel())[0, 1] for c in range(3)) > 0.99
+
+
+def _asan_tool(tmp_path, name, source):
+    """A host-only tool over cli/*.hpp built with AddressSanitizer + UBSan (the codecs read untrusted files)."""
+    src, exe = str(tmp_path / (name + ".cpp")), str(tmp_path / name)
+    open(src, "w").write(source)
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                    "-I" + os.path.join(ROOT, "cli"), src, "-o", exe, "-lz"], check=True, timeout=300)
+    return exe
+
+
+def test_hostile_jpeg_and_avi_are_refused_not_crashed(tmp_path):
+    """cli/jpeg.hpp and cli/avi.hpp read arbitrary files: over-subscribed Huffman counts, table selectors beyond 3,
+    segments shorter than their fields, truncation anywhere and random corruption must end in decode() == false (or a
+    decoded image), never in an out-of-bounds access -- checked under ASan/UBSan."""
+    import io
+    import struct
+    conv = _asan_tool(tmp_path, "imgconv_asan", open(os.path.join(ROOT, "cli", "imgconv.cpp")).read())
+    env = dict(os.environ, ASAN_OPTIONS="exitcode=99:detect_leaks=0", UBSAN_OPTIONS="halt_on_error=1:exitcode=99")
+    buf = io.BytesIO()
+    Image.fromarray(np.ascontiguousarray(synth.uw_stream(0, 1, 64, 96)[0][..., ::-1])).save(buf, format="JPEG", quality=90)
+    good = buf.getvalue()
+    out = str(tmp_path / "o.ppm")
+
+    def run(data, tag):
+        p = str(tmp_path / "h.jpg")
+        open(p, "wb").write(data)
+        r = subprocess.run([conv, p, out], capture_output=True, text=True, timeout=60, env=env)
+        assert r.returncode in (0, 1), (tag, r.returncode, r.stderr[-2000:])
+        return r.returncode
+
+    assert run(good, "good") == 0
+
+    def seg(marker):
+        i = good.index(bytes([0xFF, marker]))
+        return i, i + 2 + struct.unpack(">H", good[i + 2:i + 4])[0]
+
+    # (1) DHT whose counts over-subscribe the code space: bits[1] = 5
+    a, b = seg(0xC4)
+    bad = bytearray(good[a:b]); bad[5] = 5
+    assert run(good[:a] + bytes(bad) + good[b:], "dht oversubscribed") == 1
+    # (2) SOS table selectors 15/15
+    a, b = seg(0xDA)
+    bad = bytearray(good[a:b]); bad[6] = 0xFF
+    assert run(good[:a] + bytes(bad) + good[b:], "sos selectors") == 1
+    # (3) SOF / DRI / SOS whose length field is shorter than the fields read from them, at the end of the file
+    a, b = seg(0xC0)
+    assert run(good[:a] + b"\xff\xc0\x00\x02", "short sof") == 1
+    assert run(good[:a] + b"\xff\xc0\x00\x08" + good[a + 4:a + 10], "sof without components") == 1
+    assert run(good[:a] + b"\xff\xdd\x00\x02", "short dri") == 1
+    a2, _ = seg(0xDA)
+    assert run(good[:a2] + b"\xff\xda\x00\x03\x03", "short sos") == 1
+    # (4) truncation at every 7th byte, and seeded random corruption of header and entropy-coded bytes
+    for n in range(2, len(good), 7):
+        run(good[:n], f"truncated at {n}")
+    rng = np.random.default_rng(5)
+    for k in range(300):
+        d = bytearray(good)
+        for _ in range(int(rng.integers(1, 6))):
+            d[int(rng.integers(2, len(d)))] = int(rng.integers(0, 256))
+        run(bytes(d), f"corrupt {k}")
+
+    # AVI: LIST chunks nested 100 000 deep (12 bytes a level) and a child chunk that overruns its parent LIST
+    avi_tool = _asan_tool(tmp_path, "avi_asan", '#include "avi.hpp"\nint main(int c, char **v) { avi::Reader r; bool ok = r.open(v[1]); '
+                          'imgio::Image im; for (size_t i = 0; i < r.count(); ++i) r.read(i, im); std::printf("%zu\\n", r.count()); return ok ? 0 : 1; }\n')
+    depth = 100000
+    body = b"AVI "
+    for i in range(depth):
+        body += b"LIST" + struct.pack("<I", 4 + 12 * (depth - 1 - i)) + b"rec "
+    p = str(tmp_path / "deep.avi")
+    open(p, "wb").write(b"RIFF" + struct.pack("<I", len(body)) + body)
+    r = subprocess.run([avi_tool, p], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 1, r.stderr[-2000:]
+    inner = b"00dc" + struct.pack("<I", 4000) + good[:64]           # claims 4000 bytes inside a 76-byte LIST
+    body = b"AVI " + b"LIST" + struct.pack("<I", 4 + len(inner)) + b"movi" + inner + b"\0" * 8000
+    open(p, "wb").write(b"RIFF" + struct.pack("<I", len(body)) + body)
+    r = subprocess.run([avi_tool, p], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 1 and r.stdout.strip() == "0", (r.stdout, r.stderr[-2000:])

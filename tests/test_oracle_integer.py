@@ -276,6 +276,42 @@ def test_native_knee_matches_reference_golden():
         assert bs[f] == (2, 4, 8, 16, 32)[int(np.nonzero(ent == ent.max())[0][-1])]
 
 
+def test_native_select_host_pool_concurrent_callers():
+    """uwip_aclahe_select runs on the library's persistent host pool (no thread per call): four caller threads at once,
+    64 frames each (the bench's four sub-batch streams), give frame for frame what a one-frame-at-a-time loop gives."""
+    import ctypes as C
+    import os
+    import threading
+    from uwimageproc_amd import _native as nat
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "aclahe_knee.npz"), allow_pickle=False)
+    base = np.ascontiguousarray(g["tables"], np.float32)
+    rng = np.random.default_rng(3)
+    F = 64
+    tabs = [np.ascontiguousarray(base[rng.integers(0, len(base), F)] + rng.uniform(-1e-3, 1e-3, (F, 5, 51)).astype(np.float32)) for _ in range(4)]
+    sel = nat.lib().uwip_aclahe_select
+    exp = []
+    for t in tabs:
+        e = []
+        for f in range(F):
+            bs, cl = C.c_int32(0), C.c_int32(0)
+            assert sel(t[f:f + 1].ctypes.data_as(C.POINTER(C.c_float)), 1, C.byref(bs), C.byref(cl), None) == 0
+            e.append((bs.value, cl.value))
+        exp.append(e)
+    got = [None] * 4
+
+    def caller(i):
+        for _ in range(3):
+            bs, cl = (C.c_int32 * F)(), (C.c_int32 * F)()
+            assert sel(tabs[i].ctypes.data_as(C.POINTER(C.c_float)), F, bs, cl, None) == 0
+            got[i] = list(zip(bs, cl))
+    th = [threading.Thread(target=caller, args=(i,)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert got == exp
+
+
 def test_native_knee_matches_scipy_mirror(orc):
     import ctypes as C
     from uwimageproc_amd import _native as nat, aclahe

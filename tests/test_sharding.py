@@ -126,3 +126,48 @@ def test_stream_driver_two_ranks_equals_one(n_frames, batch):
         assert allr == r1 and allp == p1
     assert stream.select_from_ratios([0.9, 0.3, -2.0, 0.5], 0.4) == [1]
     assert stream.select_from_ratios([0.9, 0.3, -2.0, 0.5], 0.41) == [1, 2]
+
+
+def test_rank_affinity_from_sysfs(tmp_path, monkeypatch):
+    """uwimageproc_amd.affinity: the CPUs next to a rank's GPU come from the KFD topology + PCI sysfs (no GPU call);
+    two ranks on one NUMA node split its CPUs; a hidden sysfs degrades to "unavailable"."""
+    import os
+    from uwimageproc_amd import affinity
+    assert affinity.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    kfd, pci = tmp_path / "kfd", tmp_path / "pci"
+    have = sorted(os.sched_getaffinity(0))
+    half = max(1, len(have) // 2)
+    lists = [have[:half], have[:half], have[half:] or have[:1]]          # GPUs 0 and 1 share node 0
+    # node 0 is a CPU node; nodes 1..3 are GPUs at 0000:0a:00.0, 0000:1b:00.0, 0001:c3:00.0
+    locs = [(0, 0, 0), (0x0a00, 0, 1), (0x1b00, 0, 1), (0xc300, 1, 1)]
+    for i, (loc, dom, gpu) in enumerate(locs):
+        d = kfd / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if gpu else 64}\nsimd_count {1024 if gpu else 0}\nlocation_id {loc}\ndomain {dom}\n")
+    for j, bdf in enumerate(("0000:0a:00.0", "0000:1b:00.0", "0001:c3:00.0")):
+        d = pci / bdf
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{0 if j < 2 else 1}\n")
+        (d / "local_cpulist").write_text(",".join(str(c) for c in lists[j]) + "\n")
+    kw = dict(kfd_nodes=str(kfd), pci_devices=str(pci), env={})
+    assert affinity.gpu_pci_addresses(str(kfd)) == ["0000:0a:00.0", "0000:1b:00.0", "0001:c3:00.0"]
+    assert affinity.gpu_local_cpus(2, **kw)["numa_node"] == 1
+    assert affinity.gpu_local_cpus(1, kfd_nodes=str(kfd), pci_devices=str(pci), env={"HIP_VISIBLE_DEVICES": "2,0"})["pci"] == "0000:0a:00.0"
+    assert "error" in affinity.gpu_local_cpus(5, **kw)
+    assert "error" in affinity.gpu_local_cpus(0, kfd_nodes=str(tmp_path / "nope"), pci_devices=str(pci), env={})
+    before = os.sched_getaffinity(0)
+    try:
+        a = affinity.pin_rank_to_gpu(0, ranks_on_node=3, local_rank=0, **kw)
+        got0 = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, before)
+        b = affinity.pin_rank_to_gpu(1, ranks_on_node=3, local_rank=1, **kw)
+        got1 = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, before)
+        assert a["pinned"] and b["pinned"]
+        assert set(got0) <= set(lists[0]) and set(got1) <= set(lists[1])
+        if half >= 2:
+            assert not (set(got0) & set(got1))                               # the shared node's CPUs are split
+        c = affinity.pin_rank_to_gpu(0, kfd_nodes=str(tmp_path / "nope"), pci_devices=str(pci), env={})
+        assert not c["pinned"] and sorted(os.sched_getaffinity(0)) == sorted(before)
+    finally:
+        os.sched_setaffinity(0, before)

@@ -62,6 +62,13 @@ SIGNATURES = {
     "uwip_host_free": (C.c_int, [_P, _P]),
     "uwip_memcpy_h2d_async": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "uwip_memcpy_d2h_async": (C.c_int, [_P, _P, _P, C.c_size_t]),
+    "uwip_copier_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "uwip_copier_destroy": (C.c_int, [_P]),
+    "uwip_copier_upload": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "uwip_copier_download": (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.POINTER(C.c_uint64)]),
+    "uwip_copier_wait": (C.c_int, [_P, C.c_uint64]),
+    "uwip_copier_query": (C.c_int, [_P, C.c_uint64, C.POINTER(C.c_int)]),
+    "uwip_copier_last_error": (C.c_char_p, [_P]),
     "uwip_prof_enable": (C.c_int, [_P, C.c_int]),
     "uwip_prof_reset": (C.c_int, [_P]),
     "uwip_prof_count": (C.c_int, [_P, C.POINTER(C.c_int)]),
@@ -223,6 +230,59 @@ class Context:
             self.call("uwip_prof_get", i, name, 128, C.byref(ms), C.byref(cnt))
             out[name.value.decode()] = (ms.value, cnt.value)
         return out
+
+
+class Copier:
+    """Owns a ``uwip_copier``: the upload lane and the download lane of one device (include/uwip.h).  ``after`` is a
+    Context: the copy starts once everything queued on its stream at the time of the call has finished."""
+
+    def __init__(self, device: int = 0):
+        self._l = lib()
+        h = _P()
+        rc = self._l.uwip_copier_create(int(device), C.byref(h))
+        if rc != UWIP_OK:
+            raise UwipError(rc, "uwip_copier_create failed (no HIP device? there is no CPU fallback)")
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.uwip_copier_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != UWIP_OK:
+            raise UwipError(rc, self._l.uwip_copier_last_error(self._h).decode("utf-8", "replace"))
+
+    def upload(self, d_tensor, h_array, after: "Context | None" = None) -> int:
+        assert d_tensor.is_contiguous() and h_array.flags.c_contiguous
+        assert d_tensor.numel() * d_tensor.element_size() == h_array.nbytes
+        t = C.c_uint64(0)
+        self._check(self._l.uwip_copier_upload(self._h, after._h if after is not None else None, _P(d_tensor.data_ptr()),
+                                               _P(h_array.ctypes.data), h_array.nbytes, C.byref(t)))
+        return t.value
+
+    def download(self, h_array, d_tensor, after: "Context | None" = None) -> int:
+        assert d_tensor.is_contiguous() and h_array.flags.c_contiguous
+        assert d_tensor.numel() * d_tensor.element_size() == h_array.nbytes
+        t = C.c_uint64(0)
+        self._check(self._l.uwip_copier_download(self._h, after._h if after is not None else None, _P(h_array.ctypes.data),
+                                                 _P(d_tensor.data_ptr()), h_array.nbytes, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket: int):
+        self._check(self._l.uwip_copier_wait(self._h, C.c_uint64(ticket)))
+
+    def done(self, ticket: int) -> bool:
+        d = C.c_int(0)
+        self._check(self._l.uwip_copier_query(self._h, C.c_uint64(ticket), C.byref(d)))
+        return bool(d.value)
 
 
 def batch_of(t) -> BatchU8:

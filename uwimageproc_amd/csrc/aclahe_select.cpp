@@ -16,6 +16,15 @@
 #include "uwip_internal.hpp"
 #include <cmath>
 #include <cstring>
+#include <sched.h>
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <deque>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -504,6 +513,102 @@ float through_half(float f)
     return (float)h;
 }
 
+// ---- persistent host worker pool -----------------------------------------------------------------------------------------
+// One per process (= per rank), created on first use and shared by all contexts: min(16, CPUs in the process's affinity
+// mask - 1) workers (UWIP_HOST_THREADS overrides), so eight ranks that each pinned themselves to their GPU's NUMA node
+// share the host without oversubscribing it, and a step creates no threads.  parallel_for splits [0, n) into chunks that
+// the workers AND the calling thread pull from a shared counter; several callers (one per sub-batch stream) may be inside
+// at once.
+class HostPool {
+public:
+    static HostPool &get()
+    {
+        static HostPool pool;
+        return pool;
+    }
+    void parallel_for(int n, const std::function<void(int, int)> &fn)
+    {
+        if (n <= 0) return;
+        const int workers = (int)th_.size();
+        if (n < 4 || workers == 0) { fn(0, n); return; }
+        auto job = std::make_shared<Job>();
+        job->fn = &fn;
+        job->n = n;
+        job->grain = std::max(1, n / (4 * (workers + 1)));
+        job->chunks = (n + job->grain - 1) / job->grain;
+        job->left.store(job->chunks);
+        const int helpers = std::min(workers, job->chunks - 1);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (int i = 0; i < helpers; ++i) q_.push_back(job);
+        }
+        if (helpers == 1) cv_.notify_one(); else cv_.notify_all();
+        run(*job);                                           // the caller works too
+        std::unique_lock<std::mutex> lk(job->mu);
+        job->cv.wait(lk, [&] { return job->left.load() == 0; });
+    }
+
+private:
+    struct Job {
+        const std::function<void(int, int)> *fn = nullptr;
+        int n = 0, grain = 1, chunks = 0;
+        std::atomic<int> next{0}, left{0};
+        std::mutex mu;
+        std::condition_variable cv;
+    };
+    static void run(Job &j)
+    {
+        for (;;) {
+            const int c = j.next.fetch_add(1);
+            if (c >= j.chunks) return;
+            const int a = c * j.grain, b = std::min(j.n, a + j.grain);
+            (*j.fn)(a, b);
+            if (j.left.fetch_sub(1) == 1) {
+                std::lock_guard<std::mutex> lk(j.mu);
+                j.cv.notify_all();
+            }
+        }
+    }
+    HostPool()
+    {
+        int want = -1;
+        if (const char *e = std::getenv("UWIP_HOST_THREADS")) want = std::atoi(e);
+        if (want < 0) {
+            int cpus = 0;
+            cpu_set_t set;
+            if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
+            if (cpus <= 0) cpus = (int)std::thread::hardware_concurrency();
+            want = std::min(16, std::max(0, cpus - 1));
+        }
+        for (int i = 0; i < want; ++i) th_.emplace_back([this] { loop(); });
+    }
+    ~HostPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) t.join();
+    }
+    void loop()
+    {
+        for (;;) {
+            std::shared_ptr<Job> job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                job = q_.front();
+                q_.pop_front();
+            }
+            run(*job);
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::shared_ptr<Job>> q_;
+    bool stop_ = false;
+};
+
 }  // namespace
 
 UWIP_API int uwip_aclahe_knee(const float *h_xs49, const float *h_ys49, int32_t *index)
@@ -530,7 +635,7 @@ int uwip_aclahe_select_internal(const float *h_entropy, int frames, int32_t *h_b
 {
     static const int BlockSize[5] = {2, 4, 8, 16, 32};
     if (frames < 0 || (frames > 0 && (!h_entropy || !h_bs || !h_cl))) return UWIP_ERR_INVALID;
-    auto work = [&](int f0, int f1) {
+    const std::function<void(int, int)> work = [&](int f0, int f1) {
         for (int f = f0; f < f1; ++f) {
             const float *tab = h_entropy + (size_t)f * 5 * 51;
             float xs[49];
@@ -556,19 +661,8 @@ int uwip_aclahe_select_internal(const float *h_entropy, int frames, int32_t *h_b
             h_cl[f] = d;
         }
     };
-    unsigned nt = std::thread::hardware_concurrency();
-    if (nt == 0) nt = 1;
-    nt = std::min<unsigned>(nt, 16u);
-    if (frames < 4 || nt == 1) {
-        work(0, frames);
-    } else {
-        std::vector<std::thread> th;
-        const int per = (frames + (int)nt - 1) / (int)nt;
-        for (unsigned t = 0; t < nt; ++t) {
-            const int f0 = (int)t * per, f1 = std::min(frames, f0 + per);
-            if (f0 < f1) th.emplace_back(work, f0, f1);
-        }
-        for (auto &t : th) t.join();
-    }
+    // ~0.3 ms of Levenberg-Marquardt per frame: spread over the process's persistent host pool (no thread is created
+    // per call; the pool is sized from the CPUs this rank may run on, see HostPool)
+    HostPool::get().parallel_for(frames, work);
     return UWIP_OK;
 }

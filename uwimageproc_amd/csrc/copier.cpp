@@ -1,0 +1,197 @@
+// uwip_copier: the host <-> HBM copy engine of a rank (GpuMat::upload / download around the timed region,
+// modules/histretch/src/histretch.cpp:165-216, for a stream of frame batches).
+//
+// Why it exists (measured, DESIGN.md section 5 "host-buffer mode"): with one upload and one download HIP stream per
+// sub-batch (8 copy streams + 4 compute streams) the runtime multiplexes the 12 streams onto its 4 hardware queues;
+// the barrier packet behind every hipStreamWaitEvent / hipEventRecord that involves a DMA copy then sits in a queue it
+// shares with an unrelated compute stream and holds that stream's kernels for the length of the copy (7-30 ms).
+// Here no such packet exists: a lane thread waits for a request's dependency ON THE HOST, hands the copy to the DMA
+// engine when it can run, waits for it on the host, and publishes the ticket; the pipes wait for tickets on the host.
+// Copies of one direction run one at a time at the full link rate (57 GB/s), in request order.
+#include "uwip_internal.hpp"
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+struct Request {
+    void *dst;
+    const void *src;
+    size_t bytes;
+    hipEvent_t after;       // nullptr: no dependency
+    uint64_t seq;
+};
+
+struct Lane {
+    hipMemcpyKind kind;
+    hipStream_t stream = nullptr;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::deque<Request> q;
+    std::vector<hipEvent_t> free_events;
+    uint64_t next_seq = 1, done_seq = 0;
+    bool stop = false;
+};
+
+}  // namespace
+
+struct uwip_copier {
+    int device = 0;
+    Lane lane[2];           // 0 = upload, 1 = download
+    std::mutex err_mu;
+    std::string err;
+    std::atomic<bool> failed{false};
+
+    void fail(const char *what, hipError_t e)
+    {
+        std::lock_guard<std::mutex> g(err_mu);
+        if (!failed.exchange(true)) { err = what; err += ": "; err += hipGetErrorString(e); }
+    }
+    void run(Lane &L)
+    {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) fail("hipSetDevice (copy lane)", e);
+        for (;;) {
+            Request r;
+            {
+                std::unique_lock<std::mutex> lk(L.mu);
+                L.cv_work.wait(lk, [&] { return L.stop || !L.q.empty(); });
+                if (L.q.empty()) return;                    // stop requested and nothing left
+                r = L.q.front();
+            }
+            if (r.after) {
+                e = hipEventSynchronize(r.after);
+                if (e != hipSuccess) fail("hipEventSynchronize (copy dependency)", e);
+            }
+            if (!failed.load()) {
+                e = hipMemcpyAsync(r.dst, r.src, r.bytes, L.kind, L.stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(L.stream);
+                if (e != hipSuccess) fail(L.kind == hipMemcpyHostToDevice ? "upload" : "download", e);
+            }
+            {
+                std::lock_guard<std::mutex> lk(L.mu);
+                L.q.pop_front();
+                if (r.after) L.free_events.push_back(r.after);
+                L.done_seq = r.seq;
+            }
+            L.cv_done.notify_all();
+        }
+    }
+};
+
+static int submit(uwip_copier *c, int which, uwip_ctx *after, void *dst, const void *src, size_t bytes, uint64_t *ticket)
+{
+    if (!c || !ticket) return UWIP_ERR_INVALID;
+    *ticket = 0;
+    if (bytes == 0) return UWIP_OK;
+    if (!dst || !src) return UWIP_ERR_INVALID;
+    if (c->failed.load()) return UWIP_ERR_HIP;
+    Lane &L = c->lane[which];
+    hipEvent_t ev = nullptr;
+    if (after) {
+        if (after->device != c->device) return UWIP_ERR_INVALID;
+        if (int rc = uwip_enter(after)) return rc;
+        {
+            std::lock_guard<std::mutex> lk(L.mu);
+            if (!L.free_events.empty()) { ev = L.free_events.back(); L.free_events.pop_back(); }
+        }
+        // blocking-sync: the lane thread sleeps on the dependency instead of spinning
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return UWIP_ERR_HIP;
+        hipError_t e = hipEventRecord(ev, after->stream);
+        if (e != hipSuccess) { (void)hipEventDestroy(ev); return after->fail(UWIP_ERR_HIP, "hipEventRecord (copier)", hipGetErrorString(e)); }
+    }
+    {
+        std::lock_guard<std::mutex> lk(L.mu);
+        const uint64_t seq = L.next_seq++;
+        L.q.push_back(Request{dst, src, bytes, ev, seq});
+        *ticket = (seq << 1) | (uint64_t)which;
+    }
+    L.cv_work.notify_one();
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_copier_create(int device, uwip_copier **out)
+{
+    if (!out) return UWIP_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return UWIP_ERR_HIP;
+    if (device < 0 || device >= n) return UWIP_ERR_INVALID;
+    if (hipSetDevice(device) != hipSuccess) return UWIP_ERR_HIP;
+    uwip_copier *c = new (std::nothrow) uwip_copier();
+    if (!c) return UWIP_ERR_NOMEM;
+    c->device = device;
+    c->lane[0].kind = hipMemcpyHostToDevice;
+    c->lane[1].kind = hipMemcpyDeviceToHost;
+    for (auto &L : c->lane)
+        if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess) {
+            for (auto &M : c->lane) if (M.stream) (void)hipStreamDestroy(M.stream);
+            delete c;
+            return UWIP_ERR_HIP;
+        }
+    for (auto &L : c->lane) L.th = std::thread([c, &L] { c->run(L); });
+    *out = c;
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_copier_destroy(uwip_copier *c)
+{
+    if (!c) return UWIP_OK;
+    for (auto &L : c->lane) {
+        { std::lock_guard<std::mutex> lk(L.mu); L.stop = true; }
+        L.cv_work.notify_all();
+    }
+    for (auto &L : c->lane) if (L.th.joinable()) L.th.join();       // each lane finishes its queue first
+    (void)hipSetDevice(c->device);
+    for (auto &L : c->lane) {
+        for (auto ev : L.free_events) (void)hipEventDestroy(ev);
+        (void)hipStreamDestroy(L.stream);
+    }
+    delete c;
+    return UWIP_OK;
+}
+
+UWIP_API int uwip_copier_upload(uwip_copier *c, uwip_ctx *after, void *d_dst, const void *h_src, size_t bytes, uint64_t *ticket)
+{
+    return submit(c, 0, after, d_dst, h_src, bytes, ticket);
+}
+
+UWIP_API int uwip_copier_download(uwip_copier *c, uwip_ctx *after, void *h_dst, const void *d_src, size_t bytes, uint64_t *ticket)
+{
+    return submit(c, 1, after, h_dst, d_src, bytes, ticket);
+}
+
+UWIP_API int uwip_copier_wait(uwip_copier *c, uint64_t ticket)
+{
+    if (!c) return UWIP_ERR_INVALID;
+    if (ticket == 0) return UWIP_OK;
+    Lane &L = c->lane[ticket & 1];
+    const uint64_t seq = ticket >> 1;
+    std::unique_lock<std::mutex> lk(L.mu);
+    if (seq >= L.next_seq) return UWIP_ERR_INVALID;
+    L.cv_done.wait(lk, [&] { return L.done_seq >= seq; });
+    return c->failed.load() ? UWIP_ERR_HIP : UWIP_OK;
+}
+
+UWIP_API int uwip_copier_query(uwip_copier *c, uint64_t ticket, int *done)
+{
+    if (!c || !done) return UWIP_ERR_INVALID;
+    *done = 1;
+    if (ticket == 0) return UWIP_OK;
+    Lane &L = c->lane[ticket & 1];
+    std::lock_guard<std::mutex> lk(L.mu);
+    if ((ticket >> 1) >= L.next_seq) return UWIP_ERR_INVALID;
+    *done = L.done_seq >= (ticket >> 1) ? 1 : 0;
+    return c->failed.load() ? UWIP_ERR_HIP : UWIP_OK;
+}
+
+UWIP_API const char *uwip_copier_last_error(const uwip_copier *c)
+{
+    if (!c) return "null copier";
+    std::lock_guard<std::mutex> g(const_cast<uwip_copier *>(c)->err_mu);
+    return c->err.c_str();
+}

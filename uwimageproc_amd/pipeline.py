@@ -18,20 +18,23 @@ import ctypes as C
 
 import torch
 
-from ._native import Context, batch_of
+from ._native import Context, Copier, batch_of
 
 DEHAZE_FULL, DEHAZE_GUARD_S = 1, 2
 
 
 class FramePipe:
     def __init__(self, device: int, frames: int, rows: int, cols: int, letters: str = "RGB", w: int = 15,
-                 video_size=None, seed: int = 1):
+                 video_size=None, seed: int = 1, copier: "Copier | None" = None):
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         # share torch's current stream so torch events / synchronize cover our kernels
         self.stream = torch.cuda.current_stream(self.dev)
         self.ctx = Context(device, stream=self.stream.cuda_stream)
         self.host = None
+        self.timeline = None
+        self.copier, self._own_copier = copier, False
+        self._host_bufs = []
         self.F, self.H, self.W = frames, rows, cols
         self.letters, self.w, self.seed = letters.encode(), w, seed
         # the reference's globals videoWidth / videoHeight (main.cpp:238-239); as written they are the
@@ -56,9 +59,14 @@ class FramePipe:
     def close(self):
         if getattr(self, "host", None) is not None:
             self.sync()
-            self.host.up_ctx.close()
-            self.host.dn_ctx.close()
             self.host = None
+        if getattr(self, "_own_copier", False):
+            self.copier.close()
+            self.copier, self._own_copier = None, False
+        for a in getattr(self, "_host_bufs", []):
+            if a.ctypes.data in getattr(self.ctx, "_pinned", {}):
+                self.ctx.host_free(a)
+        self._host_bufs = []
         if getattr(self, "feats", None):
             self.ctx._l.uwip_features_destroy(self.feats)
             self.feats = None
@@ -107,67 +115,77 @@ class FramePipe:
 
     # ---- host-buffer front end (GpuMat::upload ... download, histretch.cpp:174-175,212-213) ------------
     def host_buffers(self):
-        """Page-locked input / output frame buffers [F,H,W,3] owned by the library."""
+        """Page-locked input / output frame buffers [F,H,W,3] owned by the library (freed by ``close``)."""
         shape = (self.F, self.H, self.W, 3)
-        return self.ctx.host_alloc(shape), self.ctx.host_alloc(shape)
+        a, b = self.ctx.host_alloc(shape), self.ctx.host_alloc(shape)
+        self._host_bufs += [a, b]
+        return a, b
+
+    def _mark(self, name):
+        """timeline instrumentation (tools/host_timeline.py): a timing event on the compute stream, kept with its name"""
+        if self.timeline is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(self.stream)
+            self.timeline.append((name, self.host.k if self.host else 0, e))
 
     def _host_state(self):
-        """Upload and download run on streams of their own, so that batch k+1 arrives and batch k leaves while the kernels
-        of batch k / k+1 run: two source buffers, two result buffers, events for the hand-overs."""
+        """Two source buffers and two result buffers in HBM, so that batch k+1 arrives and batch k leaves while the
+        kernels of batch k / k+1 run.  The copies are the copier's (one upload and one download lane per rank, shared by
+        all sub-batch pipes when one is passed in); every hand-over is a ticket waited for on the host -- no stream ever
+        waits for another one on the device (host-buffer mode)."""
         if self.host is None:
             h = type("HostState", (), {})()
-            h.up, h.dn = torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev)
-            h.up_ctx = Context(self.dev.index, stream=h.up.cuda_stream)
-            h.dn_ctx = Context(self.dev.index, stream=h.dn.cuda_stream)
+            if self.copier is None:
+                self.copier, self._own_copier = Copier(self.dev.index), True
             h.src = [torch.empty((self.F, self.H, self.W, 3), dtype=torch.uint8, device=self.dev) for _ in range(2)]
             h.work = [self.work, torch.empty_like(self.work)]
-            h.uploaded = [torch.cuda.Event() for _ in range(2)]      # src[i] holds its batch
-            h.src_free = [torch.cuda.Event() for _ in range(2)]      # the kernels that read src[i] are done
-            h.downloaded = [torch.cuda.Event() for _ in range(2)]    # work[i] has left for the host
-            h.done = torch.cuda.Event()
+            h.t_up = [0, 0]              # ticket of the upload into src[i]
+            h.t_dn = [0, 0]              # ticket of the download out of work[i]
             h.k = 0
-            h.pending = None                                         # host array whose upload into src[k % 2] is in flight
+            h.pending = None             # host array whose upload into src[k % 2] has been requested
             self.host = h
         return self.host
 
-    def _upload(self, h, slot, h_in, first):
-        if not first:
-            h.up.wait_event(h.src_free[slot])
-        h.up_ctx.h2d_async(h.src[slot], h_in)
-        h.uploaded[slot].record(h.up)
-
     def run_host(self, h_in, h_out, prefetch=None):
-        """upload -> the four stages -> download; `h_in` / `h_out` come from ``host_buffers``.  The copies run on their own
-        streams; with ``prefetch`` (the NEXT batch's input buffer) that batch is uploaded behind this one's dehaze, so a
-        stream of batches never waits for the link.  Returns without waiting (``sync()`` drains all three streams)."""
+        """upload -> the four stages -> download; `h_in` / `h_out` come from ``host_buffers``.  With ``prefetch`` (the
+        NEXT batch's input buffer) that batch's upload is requested now and runs under this batch's kernels, so a stream
+        of batches never waits for the link.  Returns (upload ticket, download ticket) without waiting for the device:
+        ``wait_ticket(t)`` blocks until that copy is complete -- `h_in` may be refilled after the first, `h_out` read
+        after the second -- and ``sync()`` drains everything."""
         h = self._host_state()
         k, slot = h.k, h.k % 2
         if h.pending is not h_in:                                    # nobody prefetched this batch
-            self._upload(h, slot, h_in, first=k < 2)
+            # src[slot] was last read by batch k-2's dehaze, which precedes everything queued on the stream now
+            h.t_up[slot] = self.copier.upload(h.src[slot], h_in, after=self.ctx if k >= 2 else None)
         h.pending = None
-        self.stream.wait_event(h.uploaded[slot])
-        if k >= 2:
-            self.stream.wait_event(h.downloaded[slot])               # work[slot] still held batch k-2 on its way out
-        self.work = h.work[slot]
-        self.stage_dehaze_histretch(h.src[slot])
-        h.src_free[slot].record(self.stream)
+        t_in = h.t_up[slot]
         if prefetch is not None:
-            self._upload(h, 1 - slot, prefetch, first=k < 1)
+            # src[1-slot] was last read by batch k-1's dehaze: the upload starts when the stream has finished batch k-1
+            h.t_up[1 - slot] = self.copier.upload(h.src[1 - slot], prefetch, after=self.ctx if k >= 1 else None)
             h.pending = prefetch
+        self.copier.wait(t_in)                                       # batch k is in HBM
+        self.copier.wait(h.t_dn[slot])                               # work[slot] (batch k-2's result) has left
+        self.work = h.work[slot]
+        self._mark("dehaze0")
+        self.stage_dehaze_histretch(h.src[slot])
+        self._mark("dehaze1")
         self.stage_aclahe()
+        self._mark("aclahe1")
         self.stage_overlap()
-        h.done.record(self.stream)
-        h.dn.wait_event(h.done)
-        h.dn_ctx.d2h_async(h_out, self.work)
-        h.downloaded[slot].record(h.dn)
+        self._mark("overlap1")
+        h.t_dn[slot] = self.copier.download(h_out, self.work, after=self.ctx)
         h.k = k + 1
+        return t_in, h.t_dn[slot]
+
+    def wait_ticket(self, ticket):
+        self.copier.wait(ticket)
 
     def sync(self):
-        """Drain the pipe's stream and, when the host-buffer front end is in use, its copy streams."""
+        """Drain the pipe's stream and, when the host-buffer front end is in use, its outstanding copies."""
         self.ctx.sync()
         if self.host is not None:
-            self.host.up_ctx.sync()
-            self.host.dn_ctx.sync()
+            for t in self.host.t_up + self.host.t_dn:
+                self.copier.wait(t)
 
     def run(self, src: torch.Tensor):
         self.stage_dehaze_histretch(src)
