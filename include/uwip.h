@@ -311,7 +311,7 @@ typedef struct uwip_keypoint {
     float   response;    /* scale-normalised determinant of the Hessian */
     int32_t level;       /* evolution level 0..3 */
     int32_t xi, yi;      /* integer extremum position */
-    int32_t pad0, pad1;
+    float   co, si;      /* unit vector of the dominant orientation ((1, 0) with UWIP_OVERLAP_UPRIGHT) */
 } uwip_keypoint;
 
 int uwip_features_create(uwip_ctx *ctx, int max_frames, uwip_features **out);
@@ -327,6 +327,12 @@ int uwip_resize_bgr(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8
 /* frames: full-resolution CV_8UC3 BGR (resized inside) or CV_8UC1 planes already at the
  * working size.  Fills slots [first_slot, first_slot + frames->frames). */
 int uwip_overlap_detect(uwip_ctx *ctx, const uwip_batch_u8 *frames, uwip_features *feats, int first_slot);
+/* Same with flags.  By default keypoints carry a dominant orientation and the descriptor is sampled in the keypoint's own
+ * frame, as the reference's SURF::create(400) is oriented (upright = false, videostrip.cpp:206-208): the overlap ratio
+ * holds under any in-plane rotation of the camera.  UWIP_OVERLAP_UPRIGHT skips the orientation estimate (SURF's
+ * `upright` parameter): rotation tolerance then ends near 20 degrees. */
+#define UWIP_OVERLAP_UPRIGHT 1u
+int uwip_overlap_detect_ex(uwip_ctx *ctx, const uwip_batch_u8 *frames, uwip_features *feats, int first_slot, unsigned flags);
 /* parity taps: one slot's keypoints (uwip_keypoint[2048]) / packed 64-byte descriptors; and the
  * scale-space images of frame `frame` of the most recent uwip_overlap_detect call (host buffers
  * of rows*cols floats, any may be NULL). */

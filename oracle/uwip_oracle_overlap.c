@@ -42,7 +42,7 @@ typedef struct {
     float response;      /* scale-normalised det of Hessian */
     int32_t level;       /* evolution level 0..3 */
     int32_t xi, yi;      /* integer extremum position */
-    int32_t pad0, pad1;
+    float co, si;        /* unit vector of the dominant orientation ((1, 0) for an upright descriptor) */
 } orc_keypoint;
 
 static const float OV_SIGMA[OV_NLEVELS] = {1.6f, 2.2627417f, 3.2f, 4.5254834f};
@@ -392,7 +392,111 @@ static int detect(const scale_space *S, orc_keypoint *kps /* OV_MAXKP */)
     return (int)nout;
 }
 
-/* ---------------- upright M-LDB descriptor (486 bits, zero padded to 512) --------- */
+/* ---------------- dominant orientation ------------------------------------------------
+ * The reference's detector is oriented SURF (SURF::create(400), upright = false,
+ * modules/videostrip/src/videostrip.cpp:206-208): an ROV yaws, so the replacement must not lose rotation invariance.
+ * AKAZE's estimate (Alcantarilla et al.): the scale-s first derivatives at the 109 lattice points of a radius-6 disc
+ * around the keypoint, Gaussian weighted (sigma 2.5), are summed inside a pi/3 sector that slides in steps of 0.15 rad;
+ * the sector with the longest sum gives the direction.  Stated here WITHOUT any angle: membership of a vector in a
+ * sector is two cross products against the sector's boundary unit vectors (tables below), and the result is the unit
+ * vector (co, si) itself -- only +, *, /, sqrt, all correctly rounded on both sides, so the device matches bit for bit.
+ * Sums run over the samples in raster order (i = x offset outer, j = y offset inner). */
+/* ORIENT-TABLES-BEGIN (generated by tools/gen_orient_tables.py, identical text in csrc/overlap.hip) */
+static const float OV_GAUSS25[7][7] = {
+    {1.0f, 0.923116326f, 0.726149023f, 0.486752242f, 0.27803731f, 0.135335281f, 0.0561347641f},
+    {0.923116326f, 0.852143764f, 0.670320034f, 0.449328959f, 0.256660789f, 0.12493021f, 0.0518189184f},
+    {0.726149023f, 0.670320034f, 0.52729243f, 0.353454679f, 0.201896518f, 0.0982735828f, 0.0407622047f},
+    {0.486752242f, 0.449328959f, 0.353454679f, 0.236927763f, 0.135335281f, 0.0658747554f, 0.0273237228f},
+    {0.27803731f, 0.256660789f, 0.201896518f, 0.135335281f, 0.0773047432f, 0.0376282558f, 0.0156075582f},
+    {0.135335281f, 0.12493021f, 0.0982735828f, 0.0658747554f, 0.0376282558f, 0.0183156393f, 0.00759701384f},
+    {0.0561347641f, 0.0518189184f, 0.0407622047f, 0.0273237228f, 0.0156075582f, 0.00759701384f, 0.00315111154f},
+};
+/* sector k: [a_k, a_k + pi/3), a_k = 0.15 k; {cos a_k, sin a_k, cos(a_k + pi/3), sin(a_k + pi/3)} */
+static const float OV_SECTOR[42][4] = {
+    {1.0f, 0.0f, 0.5f, 0.866025388f},
+    {0.988771081f, 0.149438128f, 0.36496833f, 0.931019962f},
+    {0.955336511f, 0.295520216f, 0.221740231f, 0.975105762f},
+    {0.90044713f, 0.434965521f, 0.0735323504f, 0.997292817f},
+    {0.825335622f, 0.564642489f, -0.0763269216f, 0.997082829f},
+    {0.731688857f, 0.681638777f, -0.224472046f, 0.97448051f},
+    {0.621609986f, 0.783326924f, -0.367576033f, 0.929993451f},
+    {0.497571051f, 0.867423236f, -0.502425015f, 0.864620805f},
+    {0.362357765f, 0.932039082f, -0.625990629f, 0.779830575f},
+    {0.219006687f, 0.975723386f, -0.735497892f, 0.67752701f},
+    {0.070737198f, 0.997494996f, -0.828487396f, 0.560007691f},
+    {-0.0791208893f, 0.996865034f, -0.902870893f, 0.429911822f},
+    {-0.227202088f, 0.973847628f, -0.956977844f, 0.290161043f},
+    {-0.370180845f, 0.928959727f, -0.989593148f, 0.143893853f},
+    {-0.504846096f, 0.863209367f, -0.999984264f, -0.00560486829f},
+    {-0.628173649f, 0.778073192f, -0.98791796f, -0.154977724f},
+    {-0.737393737f, 0.6754632f, -0.953665137f, -0.300870091f},
+    {-0.830053508f, 0.557683706f, -0.897995055f, -0.4400056f},
+    {-0.904072165f, 0.427379876f, -0.822157919f, -0.569259524f},
+    {-0.957787216f, 0.287478f, -0.727856874f, -0.685729086f},
+    {-0.989992499f, 0.141120002f, -0.617209733f, -0.786798656f},
+    {-0.999964654f, -0.00840724725f, -0.492701441f, -0.870198429f},
+    {-0.987479746f, -0.157745689f, -0.357128114f, -0.934055388f},
+    {-0.952818215f, -0.303541511f, -0.213534445f, -0.976935506f},
+    {-0.896758437f, -0.44252044f, -0.0651452616f, -0.99787581f},
+    {-0.820559382f, -0.571561337f, 0.0847069398f, -0.9964059f},
+    {-0.7259323f, -0.687766135f, 0.232656807f, -0.972558916f},
+    {-0.615002394f, -0.788525283f, 0.375381708f, -0.926870286f},
+    {-0.49026081f, -0.871575773f, 0.509676337f, -0.860366225f},
+    {-0.354509056f, -0.935052574f, 0.632524729f, -0.774540126f},
+    {-0.210795805f, -0.977530122f, 0.741168022f, -0.671319604f},
+    {-0.0623485148f, -0.998054445f, 0.833166242f, -0.553022623f},
+    {0.0874989852f, -0.99616462f, 0.906453371f, -0.422305971f},
+    {0.235381439f, -0.971903086f, 0.959383488f, -0.282105237f},
+    {0.377977729f, -0.925814688f, 0.990767896f, -0.135569021f},
+    {0.512085497f, -0.858934522f, 0.999901831f, 0.0140117854f},
+    {0.634692848f, -0.772764504f, 0.986580133f, 0.163277909f},
+    {0.743046463f, -0.669239879f, 0.951101959f, 0.30887717f},
+    {0.834712803f, -0.550685525f, 0.894264042f, 0.447539717f},
+    {0.907633305f, -0.419764012f, 0.817342937f, 0.57615149f},
+    {0.960170269f, -0.279415488f, 0.722066045f, 0.691824138f},
+    {0.991143942f, -0.132791907f, 0.610573113f, 0.791959882f},
+};
+/* ORIENT-TABLES-END */
+
+static void orient(const scale_space *S, orc_keypoint *k)
+{
+    const int h = S->h, w = S->w;
+    const float *Lx = S->Lx[k->level], *Ly = S->Ly[k->level];
+    const float sc = (float)OV_SSIZE[k->level];
+    float vx[109], vy[109];
+    int t = 0;
+    for (int i = -6; i <= 6; ++i)
+        for (int j = -6; j <= 6; ++j) {
+            if (i * i + j * j >= 36) continue;
+            const int x1 = clampi((int)floorf(k->x + (float)i * sc + 0.5f), 0, w - 1);
+            const int y1 = clampi((int)floorf(k->y + (float)j * sc + 0.5f), 0, h - 1);
+            const float g = OV_GAUSS25[abs(i)][abs(j)];
+            vx[t] = g * Lx[(size_t)y1 * w + x1];
+            vy[t] = g * Ly[(size_t)y1 * w + x1];
+            t++;
+        }
+    float best = 0.0f, bx = 0.0f, by = 0.0f;
+    for (int s = 0; s < 42; ++s) {
+        const float *d = OV_SECTOR[s];
+        float sx = 0.0f, sy = 0.0f;
+        for (int q = 0; q < 109; ++q) {
+            const float c1 = d[0] * vy[q] - d[1] * vx[q], c2 = d[2] * vy[q] - d[3] * vx[q];
+            if (c1 >= 0.0f && c2 < 0.0f) { sx = sx + vx[q]; sy = sy + vy[q]; }
+        }
+        const float m = sx * sx + sy * sy;
+        if (m > best) { best = m; bx = sx; by = sy; }       /* first of equal maxima */
+    }
+    if (best > 0.0f) {
+        const float nrm = sqrtf(best);
+        k->co = bx / nrm; k->si = by / nrm;
+    } else {
+        k->co = 1.0f; k->si = 0.0f;
+    }
+}
+
+/* ---------------- M-LDB descriptor (486 bits, zero padded to 512) ------------------------
+ * The 21 x 21 sample lattice and the two derivative channels are rotated by the keypoint's (co, si); with (1, 0) --
+ * upright -- every expression below reduces exactly to the unrotated one. */
 static void describe(const scale_space *S, const orc_keypoint *kps, int n, uint8_t *desc /* n*64 */)
 {
     static const int steps[3] = {10, 7, 5}, ncell1[3] = {2, 3, 4};
@@ -414,12 +518,14 @@ static void describe(const scale_space *S, const orc_keypoint *kps, int n, uint8
                     int ns = 0;
                     for (int kk = i; kk < i + st; ++kk)
                         for (int l = j; l < j + st; ++l) {
-                            const float sy = k->y + (float)l * sc, sx = k->x + (float)kk * sc;
+                            const float u = (float)kk * sc, v = (float)l * sc;
+                            const float sy = k->y + (u * k->si + v * k->co), sx = k->x + (u * k->co - v * k->si);
                             const int y1 = clampi((int)floorf(sy + 0.5f), 0, h - 1);
                             const int x1 = clampi((int)floorf(sx + 0.5f), 0, w - 1);
+                            const float rx = Lx[(size_t)y1 * w + x1], ry = Ly[(size_t)y1 * w + x1];
                             di = di + Lt[(size_t)y1 * w + x1];
-                            dx = dx + Lx[(size_t)y1 * w + x1];
-                            dy = dy + Ly[(size_t)y1 * w + x1];
+                            dx = dx + (rx * k->co + ry * k->si);          /* derivative along the keypoint's own x axis */
+                            dy = dy + (ry * k->co - rx * k->si);          /* ... and y axis */
                             ns++;
                         }
                     val[ci][0] = di / (float)ns; val[ci][1] = dx / (float)ns; val[ci][2] = dy / (float)ns;
@@ -436,15 +542,25 @@ static void describe(const scale_space *S, const orc_keypoint *kps, int n, uint8
     }
 }
 
-ORC_API int orc_detect_describe(const uint8_t *gray, int h, int w, orc_keypoint *kps, uint8_t *desc, float *kcontrast)
+/* flags: bit 0 = upright (no orientation estimate: SURF's `upright` parameter) */
+ORC_API int orc_detect_describe_ex(const uint8_t *gray, int h, int w, orc_keypoint *kps, uint8_t *desc, float *kcontrast, int flags)
 {
     scale_space S;
     build_scale_space(gray, h, w, &S);
     int n = detect(&S, kps);
+    for (int q = 0; q < n; ++q) {
+        if (flags & 1) { kps[q].co = 1.0f; kps[q].si = 0.0f; }
+        else orient(&S, &kps[q]);
+    }
     describe(&S, kps, n, desc);
     if (kcontrast) *kcontrast = S.kcontrast;
     ss_free(&S);
     return n;
+}
+
+ORC_API int orc_detect_describe(const uint8_t *gray, int h, int w, orc_keypoint *kps, uint8_t *desc, float *kcontrast)
+{
+    return orc_detect_describe_ex(gray, h, w, kps, desc, kcontrast, 0);
 }
 
 /* stage tap for parity tests: level images (each h*w floats; pointers may be NULL) */
@@ -826,8 +942,17 @@ ORC_API float orc_overlapArea(const double H[9], int videoWidth, int videoHeight
 /* ---------------- calcOverlap   videostrip.cpp:192-289 ----------------------------------- */
 /* key / obj: full-resolution BGR frames; returns the overlap ratio, -1 or -2.0 as the reference does.
  * `info` (optional, 8 ints): nkp_obj, nkp_key, ngood, ninliers, ov_count. */
+ORC_API float orc_calcOverlap_ex(const uint8_t *key, const uint8_t *obj, int rows, int cols, size_t step, int videoWidth,
+                                 int videoHeight, uint32_t seed, int32_t *info, double *Hout, int flags);
 ORC_API float orc_calcOverlap(const uint8_t *key, const uint8_t *obj, int rows, int cols, size_t step, int videoWidth,
                               int videoHeight, uint32_t seed, int32_t *info, double *Hout)
+{
+    return orc_calcOverlap_ex(key, obj, rows, cols, step, videoWidth, videoHeight, seed, info, Hout, 0);
+}
+
+/* flags: bit 0 = upright descriptors */
+ORC_API float orc_calcOverlap_ex(const uint8_t *key, const uint8_t *obj, int rows, int cols, size_t step, int videoWidth,
+                                 int videoHeight, uint32_t seed, int32_t *info, double *Hout, int flags)
 {
     if (!key || !obj || rows <= 0 || cols <= 0) return -1.0f;
     int oh, ow;
@@ -837,8 +962,8 @@ ORC_API float orc_calcOverlap(const uint8_t *key, const uint8_t *obj, int rows, 
     orc_resize_gray(obj, rows, cols, step, oh, ow, go, NULL);
     orc_keypoint *kk = (orc_keypoint *)malloc(sizeof(orc_keypoint) * OV_MAXKP), *ko = (orc_keypoint *)malloc(sizeof(orc_keypoint) * OV_MAXKP);
     uint8_t *dk = (uint8_t *)malloc((size_t)OV_MAXKP * 64), *dob = (uint8_t *)malloc((size_t)OV_MAXKP * 64);
-    int nk = orc_detect_describe(gk, oh, ow, kk, dk, NULL);
-    int no = orc_detect_describe(go, oh, ow, ko, dob, NULL);
+    int nk = orc_detect_describe_ex(gk, oh, ow, kk, dk, NULL, flags);
+    int no = orc_detect_describe_ex(go, oh, ow, ko, dob, NULL, flags);
     int32_t *idx = (int32_t *)malloc(sizeof(int32_t) * 2 * (no > 0 ? no : 1)), *dist = (int32_t *)malloc(sizeof(int32_t) * 2 * (no > 0 ? no : 1));
     int32_t *gq = (int32_t *)malloc(sizeof(int32_t) * (no > 0 ? no : 1)), *gt = (int32_t *)malloc(sizeof(int32_t) * (no > 0 ? no : 1));
     orc_match_knn2(dob, no, dk, nk, idx, dist);

@@ -45,13 +45,15 @@ class Oracle:
         L.orc_calcBlur.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t]
 
         self.KP = np.dtype([("x", "f4"), ("y", "f4"), ("response", "f4"), ("level", "i4"), ("xi", "i4"), ("yi", "i4"),
-                            ("pad0", "i4"), ("pad1", "i4")])
+                            ("co", "f4"), ("si", "f4")])
         L.orc_resize_dims.restype = None
         L.orc_resize_dims.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.orc_resize_gray.restype = None
         L.orc_resize_gray.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, u8p, C.c_void_p]
         L.orc_detect_describe.restype = C.c_int
         L.orc_detect_describe.argtypes = [u8p, C.c_int, C.c_int, C.c_void_p, u8p, C.POINTER(C.c_float)]
+        L.orc_detect_describe_ex.restype = C.c_int
+        L.orc_detect_describe_ex.argtypes = [u8p, C.c_int, C.c_int, C.c_void_p, u8p, C.POINTER(C.c_float), C.c_int]
         L.orc_scale_space_level.restype = None
         L.orc_scale_space_level.argtypes = [u8p, C.c_int, C.c_int, C.c_int, f32p, f32p, f32p, f32p]
         L.orc_match_knn2.restype = None
@@ -65,6 +67,8 @@ class Oracle:
         L.orc_calcOverlap.restype = C.c_float
         L.orc_calcOverlap.argtypes = [u8p, u8p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_uint32,
                                       C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        L.orc_calcOverlap_ex.restype = C.c_float
+        L.orc_calcOverlap_ex.argtypes = L.orc_calcOverlap.argtypes + [C.c_int]
 
         L.orc_bgr_to_hsv_px.restype = None
         L.orc_bgr_to_hsv_px.argtypes = [C.c_int] * 3 + [C.POINTER(C.c_int)] * 3
@@ -141,12 +145,12 @@ class Oracle:
         self.lib.orc_resize_gray(img, img.shape[0], img.shape[1], img.strides[0], oh, ow, g, small.ctypes.data)
         return small
 
-    def detect_describe(self, gray):
+    def detect_describe(self, gray, upright=False):
         gray = np.ascontiguousarray(gray)
         kps = np.zeros(2048, self.KP)
         desc = np.zeros((2048, 64), np.uint8)
         kc = C.c_float(0)
-        n = self.lib.orc_detect_describe(gray, gray.shape[0], gray.shape[1], kps.ctypes.data, desc, C.byref(kc))
+        n = self.lib.orc_detect_describe_ex(gray, gray.shape[0], gray.shape[1], kps.ctypes.data, desc, C.byref(kc), 1 if upright else 0)
         return kps[:n].copy(), desc[:n].copy(), kc.value
 
     def scale_space_level(self, gray, level):
@@ -180,13 +184,13 @@ class Oracle:
         r = self.lib.orc_overlapArea(Hc, vw, vh, C.byref(cnt))
         return float(r), cnt.value
 
-    def calcOverlap(self, key, obj, vw=None, vh=None, seed=1):
+    def calcOverlap(self, key, obj, vw=None, vh=None, seed=1, upright=False):
         key, obj = np.ascontiguousarray(key), np.ascontiguousarray(obj)
         vw = key.shape[1] if vw is None else vw
         vh = key.shape[0] if vh is None else vh
         info = (C.c_int32 * 8)()
         H = (C.c_double * 9)()
-        r = self.lib.orc_calcOverlap(key, obj, key.shape[0], key.shape[1], key.strides[0], vw, vh, seed, info, H)
+        r = self.lib.orc_calcOverlap_ex(key, obj, key.shape[0], key.shape[1], key.strides[0], vw, vh, seed, info, H, 1 if upright else 0)
         return float(r), list(info)[:5], np.array(list(H)).reshape(3, 3)
 
     # ---- numpy-friendly wrappers ----

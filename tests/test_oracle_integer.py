@@ -418,3 +418,30 @@ def test_colour_space_known_answers(orc):
         assert np.array_equal(fx, orc.cvt_space(conv, sp, True)) and not np.array_equal(fx, rt)
     # the older entry point and the new one agree on the spaces both know
     assert np.array_equal(orc.histretch(img, "RVGY")[0], orc.histretch_ex(img, "RVGY"))
+
+
+# ------------------------------------------------- V1/V2: rotation and zoom ----
+@pytest.mark.parametrize("theta,scale,upright,ok", [(1.0, 1.01, False, True), (30.0, 1.0, False, True), (180.0, 1.0, False, True),
+                                                    (45.0, 1.25, False, True), (0.0, 0.8, False, True), (45.0, 1.0, True, False)])
+def test_overlap_oracle_under_rotation_and_zoom(orc, theta, scale, upright, ok):
+    """The overlap design (oracle = specification) against the TRUE homography of a synthetic camera motion (SURVEY 8d:
+    translation + rotation + scale): the ratio is within the stated +-0.01 over the full circle and zoom 0.8 ... 1.25 with the
+    oriented descriptor; the upright variant (SURF's `upright`) loses it at 45 degrees -- the reference's SURF is oriented
+    (videostrip.cpp:206-208)."""
+    key, cur, H = synth.uw_motion_pair(720, 1280, theta, scale)
+    truth, _ = orc.overlapArea(synth.to_working_homography(H, 1280), 640, 480)
+    r, info, _ = orc.calcOverlap(key, cur, 640, 480, seed=1, upright=upright)
+    assert (abs(r - truth) <= 0.01) == ok, (theta, scale, r, truth, info)
+
+
+def test_motion_pair_homography_is_the_pixel_mapping():
+    """synth.uw_motion_pair's H maps current-frame pixels to key-frame pixels: a noise-free pair resampled through H agrees"""
+    key, cur, H = synth.uw_motion_pair(240, 320, 7.0, 1.05, noise=0)
+    yy, xx = np.meshgrid(np.arange(60, 180, dtype=np.float64), np.arange(80, 240, dtype=np.float64), indexing="ij")
+    X = H[0, 0] * xx + H[0, 1] * yy + H[0, 2]
+    Y = H[1, 0] * xx + H[1, 1] * yy + H[1, 2]
+    x0, y0 = np.floor(X).astype(int), np.floor(Y).astype(int)
+    fx, fy = X - x0, Y - y0
+    k = key[..., 0].astype(np.float64)
+    interp = (k[y0, x0] * (1 - fx) + k[y0, x0 + 1] * fx) * (1 - fy) + (k[y0 + 1, x0] * (1 - fx) + k[y0 + 1, x0 + 1] * fx) * fy
+    assert np.abs(interp - cur[60:180, 80:240, 0]).mean() < 1.5

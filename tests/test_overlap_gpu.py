@@ -57,9 +57,17 @@ def test_keypoints_and_descriptors_exact(ctx, orc, shape):
         assert len(kps) == len(ek) and len(kps) > 30
         for fld in ("xi", "yi", "level"):
             assert np.array_equal(kps[fld], ek[fld]), fld
-        for fld in ("x", "y", "response"):
+        for fld in ("x", "y", "response", "co", "si"):
             assert np.array_equal(kps[fld], ek[fld]), fld
         assert np.array_equal(desc, ed)
+        assert np.abs(np.hypot(kps["co"], kps["si"]) - 1.0).max() < 1e-6 and (kps["si"] != 0).mean() > 0.9
+    # SURF's `upright` parameter: no orientation estimate, (co, si) = (1, 0), the round-2 descriptor
+    f.detect(_dev(frames), upright=True)
+    kps, desc = f.download(0)
+    ek, ed, _ = orc.detect_describe(orc.resize_gray(frames[0]), upright=True)
+    assert np.array_equal(desc, ed) and np.all(kps["co"] == 1.0) and np.all(kps["si"] == 0.0)
+    ek2, ed2, _ = orc.detect_describe(orc.resize_gray(frames[0]))
+    assert not np.array_equal(ed, ed2)
 
 
 def test_gray_plane_input(ctx, orc, stream):
@@ -119,6 +127,39 @@ def test_calcOverlap_end_to_end_and_known_translation(ctx, orc, stream):
     r = vs.calcOverlap(ctx, kf, _dev(stream[1]))
     er, _, _ = orc.calcOverlap(stream[0], stream[1], 1920, 1080, seed=1)
     assert abs(r - er) <= 1e-6 and r <= 0.148
+
+
+@pytest.mark.parametrize("theta,scale", [(0.5, 1.0), (1.0, 1.01), (-1.0, 0.99), (5.0, 1.0), (20.0, 0.9), (45.0, 1.0), (90.0, 1.0),
+                                         (180.0, 1.0), (-135.0, 1.1), (0.0, 0.8), (0.0, 1.25), (45.0, 1.25)])
+def test_overlap_under_rotation_and_zoom(ctx, orc, theta, scale):
+    """consecutive frames are related by translation + rotation + scale.  The reference's detector is
+    oriented, multi-scale SURF (videostrip.cpp:206-208); the replacement must find the same overlap when the ROV yaws or
+    changes altitude.  For a camera motion with a known homography: device == oracle (1e-6), and both within the stated
+    +-0.01 of the TRUE homography pushed through the same overlapArea -- over the full circle and zoom 0.8 ... 1.25."""
+    vs.videoWidth, vs.videoHeight = 640, 480
+    key, cur, H = synth.uw_motion_pair(1080, 1920, theta, scale)
+    truth, _ = orc.overlapArea(synth.to_working_homography(H, 1920), 640, 480)
+    kf = vs.keyframe(ctx, _dev(key))
+    r = vs.calcOverlap(ctx, kf, _dev(cur), seed=1)
+    er, info, Hest = orc.calcOverlap(key, cur, 640, 480, seed=1)
+    assert abs(r - er) <= 1e-6
+    assert abs(r - truth) <= 0.01, (theta, scale, r, truth, info)
+    assert info[3] >= 40                      # inliers: a comfortable margin, not a lucky fit
+
+
+def test_upright_descriptor_envelope(ctx, orc):
+    """What the orientation buys: with UWIP_OVERLAP_UPRIGHT (round 2's descriptor) the device still equals the oracle bit
+    for bit, and both lose the overlap beyond ~20 degrees of yaw."""
+    for theta, fine in ((10.0, True), (45.0, False)):
+        key, cur, H = synth.uw_motion_pair(1080, 1920, theta, 1.0)
+        truth, _ = orc.overlapArea(synth.to_working_homography(H, 1920), 640, 480)
+        f = vs.Features(ctx, 2)
+        f.detect(_dev(np.stack([key, cur])), upright=True)
+        res = vs.match_pairs(ctx, f, f, [1], [0], 640, 480, seed=1)
+        r = float(res["ratio"].cpu()[0])
+        er, _, _ = orc.calcOverlap(key, cur, 640, 480, seed=1, upright=True)
+        assert abs(r - er) <= 1e-6
+        assert (abs(r - truth) <= 0.01) == fine, (theta, r, truth)
 
 
 def test_sentinels(ctx, orc):

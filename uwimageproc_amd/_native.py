@@ -106,6 +106,7 @@ SIGNATURES = {
     "uwip_overlap_working_size": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "uwip_resize_bgr": (C.c_int, [_P, _B, _B]),
     "uwip_overlap_detect": (C.c_int, [_P, _B, _P, C.c_int]),
+    "uwip_overlap_detect_ex": (C.c_int, [_P, _B, _P, C.c_int, C.c_uint]),
     "uwip_features_download": (C.c_int, [_P, _P, C.c_int, _P, _P, C.POINTER(C.c_int32)]),
     "uwip_features_upload": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int32]),
     "uwip_overlap_debug_level": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),

@@ -37,7 +37,8 @@ __constant__ int D_SSIZE[NLEV] = {2, 3, 5, 7};
 
 struct Keypoint {
     float x, y, response;
-    int32_t level, xi, yi, pad0, pad1;
+    int32_t level, xi, yi;
+    float co, si;        // unit vector of the dominant orientation ((1, 0): upright)
 };
 
 struct ConvK {
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(256) void k_ov_compact(const float *__restrict__ ca
             const float ox = -(Dyy * Dx - Dxy * Dy) / det, oy = -(Dxx * Dy - Dxy * Dx) / det;
             Keypoint kp;
             kp.x = (float)x + ox; kp.y = (float)y + oy; kp.response = v;
-            kp.level = lv; kp.xi = x; kp.yi = y; kp.pad0 = 0; kp.pad1 = 0;
+            kp.level = lv; kp.xi = x; kp.yi = y; kp.co = 1.0f; kp.si = 0.0f;
             kps[(size_t)f * MAXKP + pos] = kp;
         }
         __syncthreads();
@@ -577,13 +578,89 @@ __global__ __launch_bounds__(256) void k_ov_compact(const float *__restrict__ ca
     }
 }
 
-// ---- upright M-LDB: one wave per keypoint ---------------------------------------------------------------
+// ---- oriented M-LDB: one wave per keypoint ----------------------------------------------------------------
+// The reference's detector is oriented SURF (videostrip.cpp:206-208, upright = false).  Orientation: AKAZE's sliding
+// pi/3 sector over the Gaussian-weighted scale-s derivatives of a radius-6 disc, stated without angles (sector
+// membership = two cross products against tabulated boundary unit vectors; the result is the unit vector (co, si)):
+// +, *, /, sqrt only, in the oracle's order, so it is bit-exact.  Lane s < 42 owns sector s and walks the 109 samples
+// (LDS broadcast reads) sequentially = the oracle's summation order.
+/* ORIENT-TABLES-BEGIN (generated by tools/gen_orient_tables.py, identical text in oracle/uwip_oracle_overlap.c) */
+static __device__ const float D_GAUSS25[7][7] = {
+    {1.0f, 0.923116326f, 0.726149023f, 0.486752242f, 0.27803731f, 0.135335281f, 0.0561347641f},
+    {0.923116326f, 0.852143764f, 0.670320034f, 0.449328959f, 0.256660789f, 0.12493021f, 0.0518189184f},
+    {0.726149023f, 0.670320034f, 0.52729243f, 0.353454679f, 0.201896518f, 0.0982735828f, 0.0407622047f},
+    {0.486752242f, 0.449328959f, 0.353454679f, 0.236927763f, 0.135335281f, 0.0658747554f, 0.0273237228f},
+    {0.27803731f, 0.256660789f, 0.201896518f, 0.135335281f, 0.0773047432f, 0.0376282558f, 0.0156075582f},
+    {0.135335281f, 0.12493021f, 0.0982735828f, 0.0658747554f, 0.0376282558f, 0.0183156393f, 0.00759701384f},
+    {0.0561347641f, 0.0518189184f, 0.0407622047f, 0.0273237228f, 0.0156075582f, 0.00759701384f, 0.00315111154f},
+};
+/* sector k: [a_k, a_k + pi/3), a_k = 0.15 k; {cos a_k, sin a_k, cos(a_k + pi/3), sin(a_k + pi/3)} */
+static __device__ const float D_SECTOR[42][4] = {
+    {1.0f, 0.0f, 0.5f, 0.866025388f},
+    {0.988771081f, 0.149438128f, 0.36496833f, 0.931019962f},
+    {0.955336511f, 0.295520216f, 0.221740231f, 0.975105762f},
+    {0.90044713f, 0.434965521f, 0.0735323504f, 0.997292817f},
+    {0.825335622f, 0.564642489f, -0.0763269216f, 0.997082829f},
+    {0.731688857f, 0.681638777f, -0.224472046f, 0.97448051f},
+    {0.621609986f, 0.783326924f, -0.367576033f, 0.929993451f},
+    {0.497571051f, 0.867423236f, -0.502425015f, 0.864620805f},
+    {0.362357765f, 0.932039082f, -0.625990629f, 0.779830575f},
+    {0.219006687f, 0.975723386f, -0.735497892f, 0.67752701f},
+    {0.070737198f, 0.997494996f, -0.828487396f, 0.560007691f},
+    {-0.0791208893f, 0.996865034f, -0.902870893f, 0.429911822f},
+    {-0.227202088f, 0.973847628f, -0.956977844f, 0.290161043f},
+    {-0.370180845f, 0.928959727f, -0.989593148f, 0.143893853f},
+    {-0.504846096f, 0.863209367f, -0.999984264f, -0.00560486829f},
+    {-0.628173649f, 0.778073192f, -0.98791796f, -0.154977724f},
+    {-0.737393737f, 0.6754632f, -0.953665137f, -0.300870091f},
+    {-0.830053508f, 0.557683706f, -0.897995055f, -0.4400056f},
+    {-0.904072165f, 0.427379876f, -0.822157919f, -0.569259524f},
+    {-0.957787216f, 0.287478f, -0.727856874f, -0.685729086f},
+    {-0.989992499f, 0.141120002f, -0.617209733f, -0.786798656f},
+    {-0.999964654f, -0.00840724725f, -0.492701441f, -0.870198429f},
+    {-0.987479746f, -0.157745689f, -0.357128114f, -0.934055388f},
+    {-0.952818215f, -0.303541511f, -0.213534445f, -0.976935506f},
+    {-0.896758437f, -0.44252044f, -0.0651452616f, -0.99787581f},
+    {-0.820559382f, -0.571561337f, 0.0847069398f, -0.9964059f},
+    {-0.7259323f, -0.687766135f, 0.232656807f, -0.972558916f},
+    {-0.615002394f, -0.788525283f, 0.375381708f, -0.926870286f},
+    {-0.49026081f, -0.871575773f, 0.509676337f, -0.860366225f},
+    {-0.354509056f, -0.935052574f, 0.632524729f, -0.774540126f},
+    {-0.210795805f, -0.977530122f, 0.741168022f, -0.671319604f},
+    {-0.0623485148f, -0.998054445f, 0.833166242f, -0.553022623f},
+    {0.0874989852f, -0.99616462f, 0.906453371f, -0.422305971f},
+    {0.235381439f, -0.971903086f, 0.959383488f, -0.282105237f},
+    {0.377977729f, -0.925814688f, 0.990767896f, -0.135569021f},
+    {0.512085497f, -0.858934522f, 0.999901831f, 0.0140117854f},
+    {0.634692848f, -0.772764504f, 0.986580133f, 0.163277909f},
+    {0.743046463f, -0.669239879f, 0.951101959f, 0.30887717f},
+    {0.834712803f, -0.550685525f, 0.894264042f, 0.447539717f},
+    {0.907633305f, -0.419764012f, 0.817342937f, 0.57615149f},
+    {0.960170269f, -0.279415488f, 0.722066045f, 0.691824138f},
+    {0.991143942f, -0.132791907f, 0.610573113f, 0.791959882f},
+};
+/* the 109 lattice points of the radius-6 disc in the oracle's loop order (i = x offset outer, j = y offset inner) */
+static __device__ const signed char D_DISC[109][2] = {
+    {-5, -3}, {-5, -2}, {-5, -1}, {-5, 0}, {-5, 1}, {-5, 2}, {-5, 3}, {-4, -4}, {-4, -3}, {-4, -2}, {-4, -1}, {-4, 0},
+    {-4, 1}, {-4, 2}, {-4, 3}, {-4, 4}, {-3, -5}, {-3, -4}, {-3, -3}, {-3, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-3, 2},
+    {-3, 3}, {-3, 4}, {-3, 5}, {-2, -5}, {-2, -4}, {-2, -3}, {-2, -2}, {-2, -1}, {-2, 0}, {-2, 1}, {-2, 2}, {-2, 3},
+    {-2, 4}, {-2, 5}, {-1, -5}, {-1, -4}, {-1, -3}, {-1, -2}, {-1, -1}, {-1, 0}, {-1, 1}, {-1, 2}, {-1, 3}, {-1, 4},
+    {-1, 5}, {0, -5}, {0, -4}, {0, -3}, {0, -2}, {0, -1}, {0, 0}, {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5},
+    {1, -5}, {1, -4}, {1, -3}, {1, -2}, {1, -1}, {1, 0}, {1, 1}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {2, -5},
+    {2, -4}, {2, -3}, {2, -2}, {2, -1}, {2, 0}, {2, 1}, {2, 2}, {2, 3}, {2, 4}, {2, 5}, {3, -5}, {3, -4},
+    {3, -3}, {3, -2}, {3, -1}, {3, 0}, {3, 1}, {3, 2}, {3, 3}, {3, 4}, {3, 5}, {4, -4}, {4, -3}, {4, -2},
+    {4, -1}, {4, 0}, {4, 1}, {4, 2}, {4, 3}, {4, 4}, {5, -3}, {5, -2}, {5, -1}, {5, 0}, {5, 1}, {5, 2},
+    {5, 3},
+};
+/* ORIENT-TABLES-END */
 // lanes 0..28 each own one cell (4 + 9 + 16) and sum its samples sequentially (fixed order = oracle's);
 // then the 486 comparisons are spread over the 64 lanes.
 __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt, const float *__restrict__ Lx, const float *__restrict__ Ly,
-                                                   int h, int w, const Keypoint *__restrict__ kps, const int32_t *__restrict__ nkp,
-                                                   uint8_t *__restrict__ desc, int8_t *__restrict__ bits, int32_t *__restrict__ pop, int F)
+                                                   int h, int w, Keypoint *__restrict__ kps, const int32_t *__restrict__ nkp,
+                                                   uint8_t *__restrict__ desc, int8_t *__restrict__ bits, int32_t *__restrict__ pop, int F,
+                                                   int upright)
 {
+    __shared__ float s_v[2][112];
     __shared__ float s_val[29][3];
     __shared__ uint32_t s_words[16];
     __shared__ float s_patch[3][21][22];   // [plane][x offset][y offset], padded
@@ -610,16 +687,55 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
     const float *Y = Ly + ((size_t)kp.level * F + f) * npx;
     const float sc = (float)D_SSIZE[kp.level];
     if (lane < 16) s_words[lane] = 0;
+    float co = 1.0f, si = 0.0f;
+    if (!upright) {
+        for (int t = lane; t < 109; t += 64) {
+            const int i = D_DISC[t][0], j = D_DISC[t][1];
+            const int x1 = min(max((int)floorf(kp.x + (float)i * sc + 0.5f), 0), w - 1);
+            const int y1 = min(max((int)floorf(kp.y + (float)j * sc + 0.5f), 0), h - 1);
+            const float g = D_GAUSS25[abs(i)][abs(j)];
+            const size_t o = (size_t)y1 * w + x1;
+            s_v[0][t] = g * X[o];
+            s_v[1][t] = g * Y[o];
+        }
+        __syncthreads();
+        float sx = 0.0f, sy = 0.0f;
+        if (lane < 42) {
+            const float d0 = D_SECTOR[lane][0], d1 = D_SECTOR[lane][1], d2 = D_SECTOR[lane][2], d3 = D_SECTOR[lane][3];
+            for (int q2 = 0; q2 < 109; ++q2) {
+                const float vx = s_v[0][q2], vy = s_v[1][q2];
+                const float c1 = d0 * vy - d1 * vx, c2 = d2 * vy - d3 * vx;
+                if (c1 >= 0.0f && c2 < 0.0f) { sx = sx + vx; sy = sy + vy; }
+            }
+        }
+        const float m0 = sx * sx + sy * sy;
+        float m = (lane < 42 && m0 > 0.0f) ? m0 : 0.0f;     // NaN and empty sectors never win (the oracle's `m > best`)
+        int idx = lane;
+        for (int off = 32; off >= 1; off >>= 1) {             // arg-max, the lowest sector among equal maxima
+            const float om = __shfl_xor(m, off);
+            const int oi = __shfl_xor(idx, off);
+            if (om > m || (om == m && oi < idx)) { m = om; idx = oi; }
+        }
+        const float bx = __shfl(sx, idx), by = __shfl(sy, idx);
+        if (m > 0.0f) {
+            const float nrm = sqrtf(m);
+            co = bx / nrm; si = by / nrm;
+        }
+        if (lane == 0) { kps[(size_t)f * MAXKP + q].co = co; kps[(size_t)f * MAXKP + q].si = si; }
+    }
     // The three grids (2x2 cells of 10, 3x3 of 7, 4x4 of 5 samples a side) draw from one 21 x 21 lattice of sample
     // positions (offsets -10..10 times the scale): all 64 lanes fetch it once into LDS, x fastest so that a wave's
     // loads run along image rows, and the cells then sum from LDS in the oracle's order.
     for (int idx = lane; idx < 21 * 21; idx += 64) {
         const int l = idx / 21, kk = idx - l * 21;       // l: y offset index, kk: x offset index
-        const float sy = kp.y + (float)(l - 10) * sc, sx = kp.x + (float)(kk - 10) * sc;
+        // lattice and derivative pair rotated into the keypoint's frame; (co, si) = (1, 0) gives the unrotated values exactly
+        const float u = (float)(kk - 10) * sc, v = (float)(l - 10) * sc;
+        const float sy = kp.y + (u * si + v * co), sx = kp.x + (u * co - v * si);
         const int y1 = min(max((int)floorf(sy + 0.5f), 0), h - 1);
         const int x1 = min(max((int)floorf(sx + 0.5f), 0), w - 1);
         const size_t o = (size_t)y1 * w + x1;
-        s_patch[0][kk][l] = T[o]; s_patch[1][kk][l] = X[o]; s_patch[2][kk][l] = Y[o];
+        const float rx = X[o], ry = Y[o];
+        s_patch[0][kk][l] = T[o]; s_patch[1][kk][l] = rx * co + ry * si; s_patch[2][kk][l] = ry * co - rx * si;
     }
     __syncthreads();
     if (lane < 29) {
@@ -1378,7 +1494,7 @@ int alloc_work(uwip_ctx *ctx, int F, int h, int w, OvWork *W)
 // Level images are stored level-major, [NLEV][F][h][w]: every level is itself a dense batch, so the per-level
 // kernels write their results in place (no staging copies).
 // detect + describe every frame whose gray/L0 already sit in W (working size h x w)
-int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features *ft, int first_slot)
+int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features *ft, int first_slot, int upright)
 {
     const size_t n = (size_t)h * w, lvl = n * F;
     const dim3 g = grid2d(w, h, F);
@@ -1454,7 +1570,7 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
         k_ov_describe<<<8u * (((unsigned)MAXKP * F + 7u) / 8u), 64, 0, ctx->stream>>>(W.Lt, W.Lx, W.Ly, h, w, kps, nkp,
                                                              ft->d_desc + (size_t)first_slot * MAXKP * DESC_BYTES,
                                                              ft->d_bits + (size_t)first_slot * MAXKP * DESC_K,
-                                                             ft->d_pop + (size_t)first_slot * MAXKP, F);
+                                                             ft->d_pop + (size_t)first_slot * MAXKP, F, upright);
         UWIP_HIP(ctx, hipGetLastError());
     }
     return UWIP_OK;
@@ -1512,8 +1628,14 @@ UWIP_API int uwip_overlap_working_size(int rows, int cols, int *orows, int *ocol
 // is set, 8UC1 planes already at the working size.  Fills slots [first_slot, first_slot+frames).
 UWIP_API int uwip_overlap_detect(uwip_ctx *ctx, const uwip_batch_u8 *frames, uwip_features *feats, int first_slot)
 {
+    return uwip_overlap_detect_ex(ctx, frames, feats, first_slot, 0u);
+}
+
+UWIP_API int uwip_overlap_detect_ex(uwip_ctx *ctx, const uwip_batch_u8 *frames, uwip_features *feats, int first_slot, unsigned flags)
+{
     int rc = uwip_check_batch(ctx, frames, 0);
     if (rc) return rc;
+    UWIP_REQUIRE(ctx, (flags & ~(unsigned)UWIP_OVERLAP_UPRIGHT) == 0, "unknown flag");
     UWIP_REQUIRE(ctx, feats != nullptr && feats->ctx == ctx, "feature set belongs to another context");
     UWIP_REQUIRE(ctx, first_slot >= 0 && first_slot + frames->frames <= feats->capacity, "feature set too small");
     if (frames->frames == 0) return UWIP_OK;
@@ -1547,7 +1669,7 @@ UWIP_API int uwip_overlap_detect(uwip_ctx *ctx, const uwip_batch_u8 *frames, uwi
     }
     feats->w = w; feats->h = h;
     feats->frames = std::max(feats->frames, first_slot + F);
-    return detect_describe(ctx, W, F, h, w, feats, first_slot);
+    return detect_describe(ctx, W, F, h, w, feats, first_slot, (flags & UWIP_OVERLAP_UPRIGHT) ? 1 : 0);
 }
 
 // tap for tests: one slot's keypoints / packed descriptors to the host

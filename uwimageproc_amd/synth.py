@@ -99,3 +99,59 @@ def uw_stream(first: int, frames: int, rows: int, cols: int, step_frac: float = 
 def uw_stream_shift(cols: int, step_frac: float = 0.03):
     sx = max(1, int(round(step_frac * cols)))
     return sx, max(1, sx // 3)
+
+
+# ---- camera motion with a known homography (translation 2-4 % of width + rotation + scale) ---------------
+def _affine(theta_deg: float, scale: float, tx: float, ty: float, cx: float, cy: float) -> np.ndarray:
+    """frame pixel (x, y) -> texture pixel: c_tex + scale * R(theta) * ((x, y) - c) + t, as a 3x3 matrix (float64);
+    (cx, cy) is the frame centre and c_tex = the same point of the texture window at rest."""
+    th = np.deg2rad(theta_deg)
+    c, s = np.cos(th) * scale, np.sin(th) * scale
+    return np.array([[c, -s, cx - c * cx + s * cy + tx], [s, c, cy - s * cx - c * cy + ty], [0.0, 0.0, 1.0]])
+
+
+def _sample_bilinear(tex: np.ndarray, X: np.ndarray, Y: np.ndarray) -> np.ndarray:
+    x0 = np.floor(X).astype(np.int64); y0 = np.floor(Y).astype(np.int64)
+    fx = (X - x0).astype(np.float32); fy = (Y - y0).astype(np.float32)
+    x0 = np.clip(x0, 0, tex.shape[1] - 2); y0 = np.clip(y0, 0, tex.shape[0] - 2)
+    a, b = tex[y0, x0], tex[y0, x0 + 1]
+    c, d = tex[y0 + 1, x0], tex[y0 + 1, x0 + 1]
+    return (a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy
+
+
+def uw_motion_pair(rows: int, cols: int, theta_deg: float = 0.0, scale: float = 1.0, shift_frac=(0.03, 0.01), seed0: int = 1234,
+                   noise: int = 4):
+    """A key frame and a current frame of one corner-rich scene whose camera moved by a known similarity: the key frame
+    is the texture window at rest, the current frame sees the scene rotated by `theta_deg` about the frame centre,
+    zoomed by `scale` (> 1: the camera rose, features shrink) and shifted by `shift_frac` of the frame width.
+    Returns (key, cur, H) with H the exact 3x3 homography taking CURRENT-frame pixel coordinates to KEY-frame pixel
+    coordinates at full resolution (the direction findHomography(obj, scene) estimates, videostrip.cpp:270)."""
+    margin = int(0.75 * max(rows, cols))
+    tex = _texture(seed0, rows + 2 * margin, cols + 2 * margin)
+    yy, xx = np.meshgrid(np.arange(rows, dtype=np.float64), np.arange(cols, dtype=np.float64), indexing="ij")
+    cx, cy = (cols - 1) / 2.0, (rows - 1) / 2.0
+    A_key = _affine(0.0, 1.0, 0.0, 0.0, cx, cy)
+    A_cur = _affine(theta_deg, scale, shift_frac[0] * cols, shift_frac[1] * cols, cx, cy)
+    out = []
+    for k, A in enumerate((A_key, A_cur)):
+        X = A[0, 0] * xx + A[0, 1] * yy + A[0, 2] + margin
+        Y = A[1, 0] * xx + A[1, 1] * yy + A[1, 2] + margin
+        win = _sample_bilinear(tex, X, Y) * 200.0
+        rng = np.random.default_rng(seed0 + 77 + k)
+        f = np.empty((rows, cols, 3), np.float32)
+        f[..., 0] = win * 1.0 + 50.0
+        f[..., 1] = win * 0.8 + 35.0
+        f[..., 2] = win * 0.35 + 10.0
+        if noise:
+            f += rng.integers(-noise, noise + 1, size=f.shape).astype(np.float32)
+        out.append(np.clip(np.rint(f), 0, 255).astype(np.uint8))
+    H = np.linalg.inv(A_key) @ A_cur
+    return out[0], out[1], H
+
+
+def to_working_homography(H_full: np.ndarray, cols: int, target_w: int = 640) -> np.ndarray:
+    """The same homography between the 640-wide working images: cv::resize maps working pixel x_w to the full-resolution
+    position (x_w + 0.5) / f - 0.5 with f = target_w / cols (pixel centres), for both axes."""
+    f = target_w / float(cols)
+    S = np.array([[f, 0.0, 0.5 * f - 0.5], [0.0, f, 0.5 * f - 0.5], [0.0, 0.0, 1.0]])
+    return S @ H_full @ np.linalg.inv(S)

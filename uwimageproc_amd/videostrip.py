@@ -21,7 +21,7 @@ DEFAULT_KWINDOW = 11                          # videostrip.hpp:51
 videoWidth, videoHeight = 0, 0                # main.cpp:45-46
 
 KP_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("response", "f4"), ("level", "i4"), ("xi", "i4"), ("yi", "i4"),
-                     ("pad0", "i4"), ("pad1", "i4")])
+                     ("co", "f4"), ("si", "f4")])
 
 
 class Features:
@@ -44,10 +44,11 @@ class Features:
         except Exception:
             pass
 
-    def detect(self, frames: torch.Tensor, first_slot: int = 0):
+    def detect(self, frames: torch.Tensor, first_slot: int = 0, upright: bool = False):
+        """upright: SURF's `upright` parameter (no orientation estimate); the reference runs SURF oriented"""
         b = batch_of(frames)
         torch.cuda.current_stream(frames.device).synchronize()
-        self.ctx.call("uwip_overlap_detect", C.byref(b), self._h, int(first_slot))
+        self.ctx.call("uwip_overlap_detect_ex", C.byref(b), self._h, int(first_slot), 1 if upright else 0)
 
     def download(self, slot: int):
         kps = np.zeros(2048, KP_DTYPE)
