@@ -148,6 +148,41 @@ def test_sweep_histograms_exact_1080p(ctx, orc):
                 assert torch.equal(hist[0, gi, ci].to(torch.int64), exp), (g, ci)
 
 
+def test_sweep_all_255_histograms_vs_oracle_1080p(ctx, orc):
+    """BASELINE config 2's size, against the ORACLE itself (not this library's apply): all 5 x 51 output histograms of one
+    1920x1080 bench-like frame, count for count (~255 oracle CLAHE applies, a few seconds of CPU)."""
+    from concurrent.futures import ThreadPoolExecutor
+    src = _v(orc, 70, 1080, 1920)
+    _, hist = aclahe.sweep_histograms(ctx, _dev(src))
+    hist = hist.cpu().numpy()[0]
+    jobs = [(gi, ci) for gi in range(5) for ci in range(51)]
+
+    def one(j):
+        gi, ci = j
+        g = aclahe.BLOCK_SIZES[gi]
+        return np.bincount(orc.clahe(src, float(aclahe.CLIP_LIMITS[ci]), g, g).ravel(), minlength=256)
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        exp = list(ex.map(one, jobs))
+    for (gi, ci), e in zip(jobs, exp):
+        assert np.array_equal(hist[gi, ci], e), (aclahe.BLOCK_SIZES[gi], aclahe.CLIP_LIMITS[ci])
+
+
+def test_aclahe_auto_ex_vs_oracle_1080p(ctx, orc):
+    """uwip_aclahe_auto_ex end to end at 1920x1080 (BASELINE config 2), both forms of the stage: the parameters equal the
+    choice made on the oracle's own sweep table of the (pre-filtered) plane, the output equals the oracle's CLAHE of the
+    unfiltered plane with them."""
+    frames = synth.uw_stream(11, 2, 1080, 1920)
+    v = np.stack([orc.bgr_to_v(f) for f in frames])
+    t = torch.from_numpy(v).cuda()
+    for prefilter in (True, False):
+        dst, params = aclahe.auto(ctx, t, prefilter=prefilter)
+        for f in range(2):
+            src = orc.gaussian3(v[f]) if prefilter else v[f]
+            bs, cl = aclahe.select_parameters(orc.sweep(src))
+            assert params[f] == (bs, cl), (prefilter, f, params[f], (bs, cl))
+            assert np.array_equal(dst[f].cpu().numpy(), orc.clahe(v[f], float(cl), bs, bs))
+
+
 def test_sweep_histograms_exact_4k(ctx, orc):
     """3840x2160 (configs 3 / 5): the same check on one frame; at this size the 16x16 and 32x32 grids hold several cells
     per block and the 2x2 grid's cells are cut into many row chunks."""

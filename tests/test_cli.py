@@ -196,6 +196,22 @@ def test_videostrip_cli_selector_and_report(tmp_path, orc):
     c = uw.Context(0)
     got = vs.select_keyframes(c, [torch.from_numpy(f).cuda() for f in frames], minOverlap=p, kWindow=k)
     assert [(str(a), str(b)) for a, b, _, _ in got] == exp
+    # the multi-GPU form (uwimageproc_amd.selector, SURVEY 8e option 1): features and blur extracted per slice -- here the
+    # two slices a 2-rank job would take, one after the other -- then the decision chain on rank 0's GPU with speculative
+    # look-ahead: the exported IDs equal the single-GPU CLI's, and so do overlap and blur of every row
+    from uwimageproc_amd import selector, sharding
+    be = selector.GpuBackend(c, (640, 480), seed=1, lookahead=5)
+    recs = []
+    for r in range(2):
+        a, b = sharding.frame_slice(n, r, 2)
+        recs += be.extract(frames[a:b])
+    rows2 = selector.chain(recs, be.overlaps, p, k, lookahead=5)
+    assert [(str(a), str(b)) for a, b, _, _ in rows2] == exp
+    for (_, _, ov2, bl2), (_, _, ov1, bl1) in zip(rows2, got):
+        assert abs(ov2 - ov1) <= 1e-6 and abs(bl2 - bl1) <= 1e-6
+    rows3 = selector.select_distributed(be, lambda i: frames[i], n, 0, 1, p, k, batch=4, lookahead=3)
+    assert [(a, b) for a, b, _, _ in rows3] == [(a, b) for a, b, _, _ in rows2]
+    be.close()
     c.close()
     assert len(rows) >= 2 and os.path.exists(prefix + "0000.png") and os.path.exists(prefix + f"{len(rows)-1:04d}.png")
     assert np.array_equal(_load_png(prefix + "0000.png"), frames[0])

@@ -171,3 +171,113 @@ def test_rank_affinity_from_sysfs(tmp_path, monkeypatch):
         assert not c["pinned"] and sorted(os.sched_getaffinity(0)) == sorted(before)
     finally:
         os.sched_setaffinity(0, before)
+
+
+# ---- the key-frame selector across ranks (SURVEY 8e option 1) ----------------------------------------------------------
+class _OracleBackend:
+    """CPU stand-in for selector.GpuBackend: the oracle's detect / describe / blur per frame, its match + homography +
+    overlapArea per (key, frame) pair."""
+
+    def __init__(self, orc, vw, vh, seed=1):
+        self.orc, self.vw, self.vh, self.seed = orc, vw, vh, seed
+
+    def extract(self, frames):
+        out = []
+        for f in frames:
+            kps, desc, _ = self.orc.detect_describe(self.orc.resize_gray(f))
+            out.append((kps, desc, self.orc.calcBlur(self.orc.resize_bgr(f))))
+        return out
+
+    def overlaps(self, key, objs):
+        orc, res = self.orc, []
+        for kq, dq, _ in objs:
+            kt, dt, _ = key
+            r = -2.0
+            if len(kq) and len(kt):
+                idx, dist = orc.match_knn2(dq, dt)
+                gq, gt = orc.ratio_test(idx, dist, len(dt))
+                if len(gq) >= 4:
+                    n, H = orc.find_homography(kq["x"][gq], kq["y"][gq], kt["x"][gt], kt["y"][gt], 640, self.wh[0], seed=self.seed)
+                    if n > 0:
+                        r = orc.overlapArea(H, self.vw, self.vh)[0]
+            res.append(r)
+        return res
+
+
+def _reference_loop(orc, frames, p, k, vw, vh):
+    """main.cpp:300-394 frame by frame on the oracle's calcOverlap / calcBlur (what tests/test_cli.py expects of the CLI)"""
+    n = len(frames)
+    exp = [(0, 0)]
+    key, nxt, read = frames[0], 1, 1
+    while nxt < n:
+        f = frames[nxt]; nxt += 1; read += 1
+        ov, _, _ = orc.calcOverlap(key, f, vw, vh, seed=1)
+        if ov == -2.0:
+            ov = 0.41
+        if ov <= p:
+            best, bestn, bf = orc.calcBlur(orc.resize_bgr(f)), nxt - 1, f
+            eof = False
+            for _ in range(k):
+                if nxt >= n:
+                    eof = True
+                    break
+                g = frames[nxt]; nxt += 1; read += 1
+                b = orc.calcBlur(orc.resize_bgr(g))
+                if b > best:
+                    best, bestn, bf = b, read, g
+            key = bf
+            exp.append((len(exp), bestn))
+            if eof:
+                break
+    return exp
+
+
+def _selector_rank(rank, world, port, q):
+    import os
+    import sys
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world)})
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    import _oracle
+    from uwimageproc_amd import selector, synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    orc = _oracle.load()
+    frames = synth.uw_stream(0, 14, 480, 640, step_frac=0.05)
+    be = _OracleBackend(orc, 640, 480)
+    be.wh = orc.resize_dims(480, 640)
+    rows = selector.select_distributed(be, lambda i: frames[i], len(frames), rank, world, minOverlap=0.7, kWindow=2, batch=3, lookahead=4)
+    q.put((rank, [(a, b) for a, b, _, _ in rows]))
+    dist.destroy_process_group()
+
+
+def test_keyframe_selector_across_two_ranks_equals_the_sequential_loop():
+    """Two gloo ranks extract their slices, rank 0 replays the decision chain with speculative look-ahead: the exported
+    (ID, Frame) rows equal the frame-by-frame loop of main.cpp:300-394 -- the same expectation tests/test_cli.py holds
+    the single-GPU CLI to."""
+    import multiprocessing as mp
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _oracle
+    from uwimageproc_amd import selector, synth
+    orc = _oracle.load()
+    frames = synth.uw_stream(0, 14, 480, 640, step_frac=0.05)
+    exp = _reference_loop(orc, frames, 0.7, 2, 640, 480)
+    assert len(exp) >= 3
+    # single process, several look-ahead depths: speculation never changes the rows
+    be = _OracleBackend(orc, 640, 480)
+    be.wh = orc.resize_dims(480, 640)
+    recs = be.extract(frames)
+    for la in (1, 3, 8, 32):
+        assert [(a, b) for a, b, _, _ in selector.chain(recs, be.overlaps, 0.7, 2, la)] == exp, la
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29611
+    procs = [ctx.Process(target=_selector_rank, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0] == exp and got[1] == exp
