@@ -171,6 +171,17 @@ __global__ __launch_bounds__(256) void k_gauss3_u8(const uint8_t *__restrict__ s
 }
 
 // ---- C1a: tile histograms ---------------------------------------------------
+// One WAVE per (tile, row part); a block is four independent waves, no workgroup barrier.  The wave reads its rows as
+// ALIGNED dwords (4 pixels per lane and load); a tile narrower than 64 dwords is covered several rows at a time (lane ->
+// (row, dword) of a patch), so a 61-pixel tile of the 32 x 32 grid still keeps 51 of the 64 lanes busy.  Bytes of an
+// edge dword that lie outside the tile's columns are masked by a per-lane byte mask computed once.  Same-bin atomics of
+// one LDS instruction serialise (tools/ubench/lds_rand.hip: 1.7 ns with distinct banks, 53 ns with one word), and
+// neighbouring pixels of a smooth underwater frame fall into few bins: the wave's counters are replicated TH_REP times,
+// keyed by the lane index modulo TH_REP, with a replica stride of 256 + 8 words (equal bins of different replicas sit in
+// different banks).  The reflect-101 padding of a grid that does not divide the image (columns >= cols) is a per-pixel
+// loop over the few padded columns; padded rows are index math.
+constexpr int TH_REP = 4;
+constexpr int TH_RSTRIDE = 256 + 8;
 __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restrict__ src,
                                                         size_t step, size_t fstride, int rows,
                                                         int cols, int gx, int tw, int th, int split,
@@ -178,35 +189,82 @@ __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restric
                                                         const int *__restrict__ frame_map,
                                                         uint32_t *__restrict__ hists, int tiles)
 {
-    __shared__ uint32_t sh[4 * 256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 4 * 256; i += 256) sh[i] = 0;
-    __syncthreads();
-    const int t = blockIdx.x / split, part = blockIdx.x - t * split;
+    __shared__ uint32_t sh[4][TH_REP * TH_RSTRIDE];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int item = blockIdx.x * 4 + wave;
+    if (item >= tiles * split) return;
+    uint32_t *H = sh[wave];
+    for (int i = lane; i < TH_REP * TH_RSTRIDE; i += 64) H[i] = 0;
+    const int t = item / split, part = item - t * split;
     const int ty = t / gx, tx = t - ty * gx;
     const int f = blockIdx.y;
     const int fr = frame_map ? frame_map[f] : f;
     const uint8_t *base = src + (size_t)fr * fstride;
     const int j0 = part * rows_per_part, j1 = min(th, j0 + rows_per_part);
-    uint32_t *my = sh + wave * 256;
-    for (int j = j0 + wave; j < j1; j += 4) {
-        const int y = reflect101(ty * th + j, rows);
-        const uint8_t *row = base + (size_t)y * step;
-        // lane l takes pixels l*K .. l*K+K-1 (K = ceil(tw/64)): the 64 pixels of one LDS atomic are K apart, so fewer of
-        // them hit the same bin than 64 neighbours of a smooth frame would
-        const int K = (tw + 63) >> 6;
-        for (int k = 0; k < K; ++k) {
-            const int i = lane * K + k;
-            if (i < tw) {
-                int x = tx * tw + i;
-                if (x >= cols) x = reflect101(x, cols);
-                atomicAdd(&my[row[x]], 1u);
+    uint32_t *my = H + (lane % TH_REP) * TH_RSTRIDE;
+    const int xs = tx * tw, xe = max(xs, min(xs + tw, cols));   // in-image columns [xs, xe); [xe, xs + tw) is reflected padding
+    const bool vec = ((reinterpret_cast<uintptr_t>(base) | step) & 3u) == 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (xe > xs) {
+        // units along a row: aligned dwords (vec) or single pixels; the wave covers a patch of RW rows x CW units
+        const int u0 = vec ? (xs >> 2) : xs, nu = vec ? ((xe + 3) >> 2) - u0 : xe - xs;
+        const int CW = min(nu, 64), RW = 64 / CW;
+        const int r = lane / CW, c = lane - r * CW;
+        if (r < RW) {
+            for (int cb = c; cb < nu; cb += 64) {
+                const int u = u0 + cb;
+                uint32_t bmask = 0xfu;          // which bytes of the dword are columns of this tile
+                bool whole = true;              // the dword may be loaded as one (it ends inside the image row)
+                if (vec) {
+                    bmask = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) bmask |= (4 * u + k >= xs && 4 * u + k < xe) ? (1u << k) : 0u;
+                    whole = 4 * u + 4 <= cols;
+                }
+                for (int j = j0 + r; j < j1; j += RW) {
+                    const int y = reflect101(ty * th + j, rows);
+                    const uint8_t *row = base + (size_t)y * step;
+                    if (!vec) { atomicAdd(&my[row[u]], 1u); continue; }
+                    if (bmask == 0xfu) {
+                        const uint32_t w = reinterpret_cast<const uint32_t *>(row)[u];
+                        atomicAdd(&my[w & 255u], 1u); atomicAdd(&my[(w >> 8) & 255u], 1u);
+                        atomicAdd(&my[(w >> 16) & 255u], 1u); atomicAdd(&my[w >> 24], 1u);
+                    } else {
+                        uint32_t w = 0;
+                        if (whole) w = reinterpret_cast<const uint32_t *>(row)[u];
+                        else {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) if (bmask & (1u << k)) w |= (uint32_t)row[4 * u + k] << (8 * k);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) if (bmask & (1u << k)) atomicAdd(&my[(w >> (8 * k)) & 255u], 1u);
+                    }
+                }
             }
         }
     }
-    __syncthreads();
-    const uint32_t s = sh[tid] + sh[256 + tid] + sh[512 + tid] + sh[768 + tid];
-    if (s) atomicAdd(&hists[((size_t)f * tiles + t) * 256 + tid], s);
+    // reflected padding columns [xe, xs + tw): a handful per row
+    const int npad = xs + tw - xe;
+    if (npad > 0) {
+        for (int i = lane; i < npad * (j1 - j0); i += 64) {
+            const int jr = i / npad, x = xe + (i - jr * npad);
+            const int y = reflect101(ty * th + j0 + jr, rows);
+            atomicAdd(&my[base[(size_t)y * step + reflect101(x, cols)]], 1u);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t *out = hists + ((size_t)f * tiles + t) * 256;
+    for (int bn = lane; bn < 256; bn += 64) {
+        uint32_t sum = 0;
+#pragma unroll
+        for (int q = 0; q < TH_REP; ++q) sum += H[q * TH_RSTRIDE + bn];
+        if (split == 1) out[bn] = sum;                  // the only writer: no memset, no atomic
+        else if (sum) atomicAdd(&out[bn], sum);
+    }
 }
 
 // Histograms of a g x g grid from those of the 2g x 2g grid when neither is padded (a tile is then exactly four
@@ -279,7 +337,8 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
             }
             w = lut_word(h);
         }
-        *reinterpret_cast<uint32_t *>(luts + (((size_t)f * ncl + c) * tiles + t) * 256 + lane * 4) = w;
+        // [frame][tile][clip limit][256]: the wave's rows are one contiguous run (ncl = 1: the plain [frame][tile][256] table)
+        *reinterpret_cast<uint32_t *>(luts + (((size_t)f * tiles + t) * ncl + c) * 256 + lane * 4) = w;
     }
 }
 
@@ -467,7 +526,7 @@ __device__ __forceinline__ void sweep_run(const uint32_t *pack_v, uint32_t *my_h
 __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__restrict__ src, size_t step,
                                                      size_t fstride, int gx, int gy, float inv_tw,
                                                      float inv_th,
-                                                     const uint8_t *__restrict__ luts /*[F][51][tiles][256]*/,
+                                                     const uint8_t *__restrict__ luts /*[F][tiles][51][256]*/,
                                                      const CellItem *__restrict__ items, int nitems,
                                                      int items_per_block,
                                                      uint32_t *__restrict__ out_hist /*[F][51][256]*/,
@@ -498,7 +557,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
     for (int i = tid; i < SWEEP_REP * SWEEP_RSTRIDE + SWEEP_TROWS * 256; i += SWEEP_THREADS) s_hist[i] = 0;
     uint32_t *my_hist = s_hist + (tid % SWEEP_REP) * SWEEP_RSTRIDE;
     const uint8_t *fb = src + (size_t)f * fstride;
-    const uint8_t *L = luts + ((size_t)f * SWEEP_NCL + (size_t)cg * SWEEP_GROUP) * tiles * 256;
+    const uint8_t *L = luts + ((size_t)f * tiles * SWEEP_NCL + (size_t)cg * SWEEP_GROUP) * 256;      // + (tile * 51 + c) * 256
     for (int it = i0; it < i1; ++it) {
         const CellItem ci = items[it];
         const int tx1 = max(ci.cx - 1, 0), tx2 = min(ci.cx, gx - 1);
@@ -521,11 +580,11 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
         // never read
         for (int idx = tid; idx < nd * 64; idx += SWEEP_THREADS) {
             const int c = idx >> 6, v4 = idx & 63;
-            const uint32_t *Lc = reinterpret_cast<const uint32_t *>(L + (size_t)c * tiles * 256);
-            const uint32_t a = Lc[((size_t)ty1 * gx + tx1) * 64 + v4];
-            const uint32_t b = Lc[((size_t)ty1 * gx + tx2) * 64 + v4];
-            const uint32_t cc = Lc[((size_t)ty2 * gx + tx1) * 64 + v4];
-            const uint32_t d = Lc[((size_t)ty2 * gx + tx2) * 64 + v4];
+            const uint32_t *Lc = reinterpret_cast<const uint32_t *>(L + (size_t)c * 256);
+            const uint32_t a = Lc[((size_t)ty1 * gx + tx1) * (SWEEP_NCL * 64) + v4];
+            const uint32_t b = Lc[((size_t)ty1 * gx + tx2) * (SWEEP_NCL * 64) + v4];
+            const uint32_t cc = Lc[((size_t)ty2 * gx + tx1) * (SWEEP_NCL * 64) + v4];
+            const uint32_t d = Lc[((size_t)ty2 * gx + tx2) * (SWEEP_NCL * 64) + v4];
             const uint32_t t0 = __builtin_amdgcn_perm(b, a, 0x05010400u), t1 = __builtin_amdgcn_perm(b, a, 0x07030602u);
             const uint32_t u0 = __builtin_amdgcn_perm(d, cc, 0x05010400u), u1 = __builtin_amdgcn_perm(d, cc, 0x07030602u);
             reinterpret_cast<uint4 *>(s_pack)[idx] =
@@ -668,11 +727,13 @@ int launch_tilehist(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g,
                     int nf, uint32_t *d_hists)
 {
     const int tiles = g.gx * g.gy;
-    UWIP_HIP(ctx, hipMemsetAsync(d_hists, 0, sizeof(uint32_t) * 256 * (size_t)tiles * nf, ctx->stream));
-    int split = (int)((4096 + (size_t)tiles * nf - 1) / ((size_t)tiles * nf));
+    // one wave per (tile, row part): enough parts for >= 16384 waves, at least 8 rows each
+    int split = (int)((16384 + (size_t)tiles * nf - 1) / ((size_t)tiles * nf));
     split = std::max(1, std::min(split, std::max(1, g.th / 8)));
     const int rpp = (g.th + split - 1) / split;
-    dim3 grid((unsigned)(tiles * split), (unsigned)nf);
+    split = (g.th + rpp - 1) / rpp;                       // no empty parts
+    if (split > 1) UWIP_HIP(ctx, hipMemsetAsync(d_hists, 0, sizeof(uint32_t) * 256 * (size_t)tiles * nf, ctx->stream));
+    dim3 grid((unsigned)((tiles * split + 3) / 4), (unsigned)nf);
     uwip_kscope ks(ctx, "k_clahe_tilehist");
     k_clahe_tilehist<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
                                                     g.rows, g.cols, g.gx, g.tw, g.th, split, rpp,
