@@ -20,6 +20,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A rank has four
+# sub-batch streams, the two copier lanes and the default stream: with 4 queues two sub-batch streams share one and
+# run strictly one after the other (measured: 2650 frames/s with 4 queues, 2750 with 8 or 16).  Must be set before the
+# runtime initialises; a deployment sets it the same way.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
