@@ -21,10 +21,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # The HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A rank has four
-# sub-batch streams, the two copier lanes and the default stream: with 4 queues two sub-batch streams share one and
-# run strictly one after the other (measured: 2650 frames/s with 4 queues, 2750 with 8 or 16).  Must be set before the
+# sub-batch streams, the two copier lanes and the default stream: with 4 queues sub-batch streams share one and run
+# strictly one after the other (measured, 4 sub-batches of 64 frames: 2650 frames/s with 4 queues, 2750 with 8 or 16;
+# 8 sub-batches of 64 frames on 16 queues: 2880).  Must be set before the
 # runtime initialises; a deployment sets it the same way.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -40,13 +41,13 @@ def parse():
     ap.add_argument("--config", choices=["1080p", "4k", "4k-paced"], default="1080p",
                     help="1080p: BASELINE.json's metric (default); 4k: the same pipe on 3840x2160 frames (configs 3/5), 64 frames per "
                          "step; 4k-paced: config 5's stream mode -- 600 frames arriving at 60 fps through host buffers, then unpaced")
-    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 256 at 1080p, 64 at 4K)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 512 at 1080p, 64 at 4K)")
     ap.add_argument("--rows", type=int, default=None)
     ap.add_argument("--cols", type=int, default=None)
     ap.add_argument("--paced-fps", type=float, default=60.0)
     ap.add_argument("--paced-frames", type=int, default=600)
     ap.add_argument("--paced-batch", type=int, default=4, help="frames gathered before the pipe runs (latency vs launch size)")
-    ap.add_argument("--streams", type=int, default=4, help="independent sub-batches in flight per GPU (HIP streams + host threads)")
+    ap.add_argument("--streams", type=int, default=8, help="independent sub-batches in flight per GPU (HIP streams + host threads)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matcher-bench", dest="matcher_bench", action="store_false",
                     help="skip the 2048 x 2048 matcher measurement (MFMA utilisation on BASELINE config 4's size)")
@@ -63,7 +64,7 @@ def parse():
     big = a.config != "1080p"
     a.rows = a.rows or (2160 if big else 1080)
     a.cols = a.cols or (3840 if big else 1920)
-    a.frames = a.frames or (64 if big else 256)
+    a.frames = a.frames or (64 if big else 512)
     return a
 
 

@@ -248,18 +248,7 @@ __global__ void k_ov_kc_final(const uint32_t *__restrict__ hmax_bits, const uint
     kc[f] = nelements < nthreshold ? 0.03f : hmax * ((float)k / 300.0f);
 }
 
-// ---- Perona-Malik g2 conductivity ------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ov_flow(const float *__restrict__ Lsm, const float *__restrict__ kc, float *__restrict__ flow, int h, int w)
-{
-    const int f = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
-    const float k = kc[f];
-    const float inv_k = 1.0f / (k * k);
-    float gx, gy;
-    scharr_at(Lsm + (size_t)f * h * w, h, w, y, x, gx, gy);
-    flow[((size_t)f * h + y) * w + x] = 1.0f / (1.0f + (gx * gx + gy * gy) * inv_k);
-}
+// (the Perona-Malik g2 conductivity is written by k_ov_deriv1, which reads the same smoothed plane)
 
 // ---- one explicit FED diffusion step ----------------------------------------------------------
 __global__ __launch_bounds__(256) void k_ov_fed(const float *__restrict__ Lin, const float *__restrict__ cin, float *__restrict__ out,
@@ -339,6 +328,54 @@ __global__ __launch_bounds__(256) void k_ov_fed2(const float *__restrict__ Lin, 
     }
 }
 
+// NS consecutive FED steps in one launch (NS <= FDN_MAX): the tile + NS halo pixels of L and of the conductivity are staged
+// once (edge-clamped loads), every step shrinks the valid region by one pixel, ping-ponging between two LDS planes.  A
+// neighbour index is clamped INSIDE THE IMAGE before it is turned into a plane index -- k_ov_fed's border rule -- so values
+// computed at out-of-image halo positions are never read.  Same operations in the same order as NS launches of k_ov_fed;
+// the planes travel through L2 / HBM once instead of NS times.
+constexpr int FDN_MAX = 4;
+struct FedTaus { float t[FDN_MAX]; };
+template <int NS>
+__global__ __launch_bounds__(256) void k_ov_fedn(const float *__restrict__ Lin, const float *__restrict__ cin, float *__restrict__ out,
+                                                int h, int w, FedTaus taus)
+{
+    constexpr int W2 = FD_TW + 2 * NS, H2 = FD_TH + 2 * NS;
+    __shared__ float s_c[H2 * W2], s_A[H2 * W2], s_B[H2 * W2];
+    const int f = blockIdx.z, x0 = blockIdx.x * FD_TW - NS, y0 = blockIdx.y * FD_TH - NS;   // image coordinates of plane (0, 0)
+    const float *L = Lin + (size_t)f * h * w, *c = cin + (size_t)f * h * w;
+    for (int i = threadIdx.x; i < H2 * W2; i += 256) {
+        const int ry = i / W2, rx = i - ry * W2;
+        const int y = min(max(y0 + ry, 0), h - 1), x = min(max(x0 + rx, 0), w - 1);
+        s_A[i] = L[(size_t)y * w + x];
+        s_c[i] = c[(size_t)y * w + x];
+    }
+    __syncthreads();
+    float *src = s_A, *dst = s_B;
+#pragma unroll
+    for (int k = 1; k <= NS; ++k) {
+        const float step = 0.5f * taus.t[k - 1];
+        const int RW = W2 - 2 * k, RH = H2 - 2 * k;          // region of this step: plane coordinates [k, W2 - k) x [k, H2 - k)
+        for (int i = threadIdx.x; i < RH * RW; i += 256) {
+            const int ry = i / RW + k, rx = i - (i / RW) * RW + k;
+            const int x = x0 + rx, y = y0 + ry;
+            const int xm = min(max(x - 1, 0), w - 1) - x0, xp = min(max(x + 1, 0), w - 1) - x0;
+            const int ym = min(max(y - 1, 0), h - 1) - y0, yp = min(max(y + 1, 0), h - 1) - y0;
+            // an out-of-image position has its neighbour indices clamped onto in-plane positions as well (|delta| <= 1 from
+            // a clamped coordinate): harmless, its value is never used
+            const int o = ry * W2 + rx;
+            const int oxm = ry * W2 + min(max(xm, 0), W2 - 1), oxp = ry * W2 + min(max(xp, 0), W2 - 1);
+            const int oym = min(max(ym, 0), H2 - 1) * W2 + rx, oyp = min(max(yp, 0), H2 - 1) * W2 + rx;
+            const float v = fed_px(src[o], src[oxm], src[oxp], src[oym], src[oyp], s_c[o], s_c[oxm], s_c[oxp], s_c[oym], s_c[oyp], step);
+            if (k < NS) dst[o] = v;
+            else if (x < w && y < h) out[((size_t)f * h + y) * w + x] = v;   // k == NS: the region is the tile itself
+        }
+        if (k < NS) {
+            __syncthreads();
+            float *t = src; src = dst; dst = t;
+        }
+    }
+}
+
 // ---- scale-s first derivative (taps at -s, 0, +s) ------------------------------------------------
 __device__ __forceinline__ float deriv_at(const float *I, int h, int w, int y, int x, int s, bool along_x)
 {
@@ -360,7 +397,10 @@ __device__ __forceinline__ float deriv_at(const float *I, int h, int w, int y, i
     return (t0 + t1) + t2;
 }
 
-__global__ __launch_bounds__(256) void k_ov_deriv1(const float *__restrict__ Lsm, float *__restrict__ Lx, float *__restrict__ Ly, int h, int w, int s)
+// also writes the Perona-Malik conductivity of the same smoothed plane when `flow` is given (k_ov_flow's arithmetic: the
+// two kernels read the same plane, one launch and one read of it instead of two)
+__global__ __launch_bounds__(256) void k_ov_deriv1(const float *__restrict__ Lsm, float *__restrict__ Lx, float *__restrict__ Ly, int h, int w, int s,
+                                                  const float *__restrict__ kc, float *__restrict__ flow)
 {
     const int f = blockIdx.z;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -369,6 +409,13 @@ __global__ __launch_bounds__(256) void k_ov_deriv1(const float *__restrict__ Lsm
     const size_t o = ((size_t)f * h + y) * w + x;
     Lx[o] = deriv_at(I, h, w, y, x, s, true);
     Ly[o] = deriv_at(I, h, w, y, x, s, false);
+    if (flow) {
+        const float k = kc[f];
+        const float inv_k = 1.0f / (k * k);
+        float gx, gy;
+        scharr_at(I, h, w, y, x, gx, gy);
+        flow[o] = 1.0f / (1.0f + (gx * gx + gy * gy) * inv_k);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_ov_ldet(const float *__restrict__ Lx, const float *__restrict__ Ly, float *__restrict__ Ldet, int h, int w, int s)
@@ -1519,28 +1566,30 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
                 k_ov_kc_final<<<uwip_cdiv(F, 64), 64, 0, ctx->stream>>>(W.hmax, W.khist, W.kc, F);
             }
             const int s = H_SSIZE[lv];
-            k_ov_deriv1<<<g, 256, 0, ctx->stream>>>(W.Lsm, W.Lx + lv * lvl, W.Ly + lv * lvl, h, w, s);
+            k_ov_deriv1<<<g, 256, 0, ctx->stream>>>(W.Lsm, W.Lx + lv * lvl, W.Ly + lv * lvl, h, w, s, W.kc, lv + 1 < NLEV ? W.flow : nullptr);
             k_ov_ldet<<<g, 256, 0, ctx->stream>>>(W.Lx + lv * lvl, W.Ly + lv * lvl, W.Ldet + lv * lvl, h, w, s);
             if (lv + 1 < NLEV) {
-                k_ov_flow<<<g, 256, 0, ctx->stream>>>(W.Lsm, W.kc, W.flow, h, w);
                 const float e0 = 0.5f * H_SIGMA[lv] * H_SIGMA[lv], e1 = 0.5f * H_SIGMA[lv + 1] * H_SIGMA[lv + 1];
                 float taus[32];
                 const int nt = fed_taus(e1 - e0, taus);
-                // two steps per launch (one for an odd remainder); ping-pong between Lt[lv+1] and a scratch plane so
-                // that the last launch lands in Lt[lv+1]
+                // up to FDN_MAX steps per launch, split as evenly as possible (8 -> 4 + 4, 6 -> 3 + 3, 4 -> 4); ping-pong
+                // between Lt[lv+1] and a scratch plane so that the last launch lands in Lt[lv+1]
                 float *next = W.Lt + (lv + 1) * lvl;
                 const float *src = Lt;
-                const int nl = (nt + 1) / 2;
+                const int nl = (nt + FDN_MAX - 1) / FDN_MAX;
                 const dim3 gf(uwip_cdiv(w, FD_TW), uwip_cdiv(h, FD_TH), (unsigned)F);
                 for (int j = 0, k = 0; j < nl; ++j) {
                     float *dst = ((nl - j) & 1) ? next : W.ping;
-                    if (k + 1 < nt) {
-                        k_ov_fed2<<<gf, 256, 0, ctx->stream>>>(src, W.flow, dst, h, w, taus[k], taus[k + 1]);
-                        k += 2;
-                    } else {
-                        k_ov_fed<<<g, 256, 0, ctx->stream>>>(src, W.flow, dst, h, w, taus[k]);
-                        k += 1;
+                    const int ns = (nt - k + (nl - j) - 1) / (nl - j);
+                    FedTaus tk;
+                    for (int q = 0; q < FDN_MAX; ++q) tk.t[q] = q < ns ? taus[k + q] : 0.0f;
+                    switch (ns) {
+                    case 1: k_ov_fed<<<g, 256, 0, ctx->stream>>>(src, W.flow, dst, h, w, taus[k]); break;
+                    case 2: k_ov_fed2<<<gf, 256, 0, ctx->stream>>>(src, W.flow, dst, h, w, taus[k], taus[k + 1]); break;
+                    case 3: k_ov_fedn<3><<<gf, 256, 0, ctx->stream>>>(src, W.flow, dst, h, w, tk); break;
+                    default: k_ov_fedn<4><<<gf, 256, 0, ctx->stream>>>(src, W.flow, dst, h, w, tk); break;
                     }
+                    k += ns;
                     src = dst;
                 }
             }
