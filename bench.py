@@ -231,7 +231,7 @@ def stage_of(kernel):
 def pmc_entry(kernel, rows, cols):
     """Committed counter digest of the same command (tools/pmc_digest.py over separate rocprofv3 --pmc passes; the
     counters cannot be read inside this process).  None when no matching profile is committed."""
-    for name in ("r02_pmc.json",):
+    for name in ("r03_pmc.json", "r02_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             e = d.get(f"{cols}x{rows}", {}).get(kernel)
@@ -303,6 +303,8 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
         traffic = None if e is None else e["hbm_bytes_per_frame"] * frames_per_launch
         return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else traffic / per_launch,
+                "traffic_source": None if e is None else "committed rocprofv3 --pmc passes of the same command (profiles/r03_pmc.json: "
+                                  "2 x FETCH_SIZE + WRITE_SIZE per launch), not re-measured in this run",
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch}
 
     # (1) the CLAHE kernel named by north_star: the final per-frame apply (read N + write N per frame), as launched
@@ -331,7 +333,33 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
         big = hbm_entry("k_clahe_apply", 2.0 * N, big_f, ms2, cnt2)
         big["working_set"] = f"one launch over {big_f} frames = {2.0 * N * big_f / 1e9:.2f} GB (> 256 MB Infinity Cache), CLAHE(3.0, 8x8)"
         roof["large_working_set"] = big
-        del vin, vout
+
+        # (1c) SURVEY 8(d)'s "CLAHE kernel" is the whole apply of cv::CLAHE: 3N = read N (tile histograms) + read N + write N
+        # (interpolation).  All kernels of one uwip_clahe call: tile histograms + clip / LUT + pack + interpolation.
+        def whole(r, frames, label):
+            parts = {k: r[k][0] / r[k][1] for k in ("k_clahe_tilehist", "k_clahe_lut", "k_clahe_pack", "k_clahe_apply") if k in r}
+            t_ms = sum(parts.values())
+            ach = 3.0 * N * frames / (t_ms * 1e-3) / 1e9
+            return {"bound": "hbm", "kernels": {k: v * 1e3 for k, v in parts.items()}, "kernel_time_unit": "us per launch", "frames": frames,
+                    "algorithmic_bytes": 3.0 * N * frames, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "workload": label}
+        whole_big = whole(r2, big_f, f"uwip_clahe(3.0, 8x8) on {big_f} frames in one call")
+        per_grid = {}
+        vs = vin[:Fs]
+        vo = vout[:Fs]
+        ib, ob = batch_of(vs), batch_of(vo)
+        for g_ in (8, 32):
+            ctx.call("uwip_clahe", C.byref(ib), C.byref(ob), C.c_double(3.0), g_, g_, 0)
+            ctx.sync()
+            ctx.prof_reset(); ctx.prof_enable(True)
+            for _ in range(3):
+                ctx.call("uwip_clahe", C.byref(ib), C.byref(ob), C.c_double(3.0), g_, g_, 0)
+            ctx.sync()
+            r3 = ctx.prof_results()
+            ctx.prof_enable(False)
+            per_grid[f"{g_}x{g_}"] = whole(r3, Fs, f"uwip_clahe(3.0, {g_}x{g_}) on {Fs} frames (one sub-batch)")
+        roof["clahe_whole"] = {"large_working_set": whole_big, "sub_batch": per_grid}
+        del vin, vout, vs, vo
     except Exception as e:                                    # never lose the bench line over the side measurement
         roof["large_working_set"] = {"error": str(e)[:200]}
     # (2) the kernel with the largest share of the step

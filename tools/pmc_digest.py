@@ -81,7 +81,10 @@ def main():
         if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
             e["hbm_bytes_per_frame"] = (2.0 * avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024 / a.frames
             e["fetch_KB_per_launch"], e["write_KB_per_launch"] = avg["FETCH_SIZE"], avg["WRITE_SIZE"]
-            e["note"] = "FETCH_SIZE doubled (gfx950 wide-read correction, MI355X_MICROARCH.md HBM section)"
+            e["hbm_bytes_per_frame_fetch_as_reported"] = (avg["FETCH_SIZE"] + avg["WRITE_SIZE"]) * 1024 / a.frames
+            e["note"] = ("FETCH_SIZE doubled (gfx950, MI355X_MICROARCH.md HBM section).  Calibration in this code base: k_bgr_to_v reads "
+                         "exactly 3 B/px and k_hsv_replace_v 4 B/px with dword / dwordx2 loads, and both report half of that; byte-wide "
+                         "loads (the pixel reads of k_clahe_sweep) are not calibrated: hbm_bytes_per_frame_fetch_as_reported is the lower bound")
         for c, key in (("SQ_INSTS_VALU", "valu_insts_per_frame"), ("SQ_INSTS_LDS", "lds_insts_per_frame"), ("SQ_INSTS_SALU", "salu_insts_per_frame"),
                        ("SQ_LDS_IDX_ACTIVE", "lds_idx_active_per_frame"), ("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict_per_frame"),
                        ("SQ_ACTIVE_INST_VALU", "valu_active_quadcycles_per_frame"), ("SQ_WAVE_CYCLES", "wave_quadcycles_per_frame")):

@@ -10,7 +10,7 @@ tag=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 echo "bench (default)"; timeout -k 10 500 python3 bench.py > gpurun_out/bench_${tag}.json 2> gpurun_out/bench_${tag}.err
 echo "bench (4k-paced)"; timeout -k 10 500 python3 bench.py --config 4k-paced --no-cpu-baseline --no-matcher-bench > gpurun_out/bench4k_${tag}.json 2> gpurun_out/bench4k_${tag}.err
-B="python3 bench.py --steps 3 --warmup 1 --streams 1 --frames 64 --no-cpu-baseline --no-host-buffers --no-matcher-bench --no-large-working-set"
+B="python3 bench.py --steps 3 --warmup 1 --streams 1 --frames 64 --no-cpu-baseline --no-host-buffers --no-matcher-bench --no-large-working-set --no-4k"
 echo "kernel stats"; timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_${tag} --output-format csv -- $B > gpurun_out/prof_${tag}.log 2>&1
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
