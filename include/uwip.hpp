@@ -47,6 +47,39 @@ private:
     uwip_ctx *ctx_ = nullptr;
 };
 
+// The rank's copy engine (uwip_copier): upload / download of frame batches between page-locked host buffers and HBM on
+// two lanes of their own, hand-overs by ticket (GpuMat::upload / download with a cuda::Stream around the timed region,
+// histretch.cpp:165-216, for a stream of batches).  `after`: the copy starts once everything queued on that context's
+// stream so far has finished.
+class Copier {
+public:
+    explicit Copier(int device = 0)
+    {
+        int rc = uwip_copier_create(device, &c_);
+        if (rc != UWIP_OK) throw Error(rc, "uwip_copier_create failed: no HIP device (there is no CPU fallback)");
+    }
+    ~Copier() { uwip_copier_destroy(c_); }
+    Copier(const Copier &) = delete;
+    Copier &operator=(const Copier &) = delete;
+    uint64_t upload(void *d_dst, const void *h_src, size_t bytes, Context *after = nullptr)
+    {
+        uint64_t t = 0;
+        check(uwip_copier_upload(c_, after ? after->get() : nullptr, d_dst, h_src, bytes, &t));
+        return t;
+    }
+    uint64_t download(void *h_dst, const void *d_src, size_t bytes, Context *after = nullptr)
+    {
+        uint64_t t = 0;
+        check(uwip_copier_download(c_, after ? after->get() : nullptr, h_dst, d_src, bytes, &t));
+        return t;
+    }
+    void wait(uint64_t ticket) { check(uwip_copier_wait(c_, ticket)); }
+    bool done(uint64_t ticket) { int d = 0; check(uwip_copier_query(c_, ticket, &d)); return d != 0; }
+private:
+    void check(int rc) const { if (rc != UWIP_OK) throw Error(rc, uwip_copier_last_error(c_)); }
+    uwip_copier *c_ = nullptr;
+};
+
 // device copy of a host Mat (the role cv::cuda::GpuMat plays in the reference's CUDA branches)
 class DeviceMat {
 public:

@@ -373,3 +373,12 @@ def test_hostile_jpeg_and_avi_are_refused_not_crashed(tmp_path):
     open(p, "wb").write(b"RIFF" + struct.pack("<I", len(body)) + body)
     r = subprocess.run([avi_tool, p], capture_output=True, text=True, timeout=60, env=env)
     assert r.returncode == 1 and r.stdout.strip() == "0", (r.stdout, r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_copier_from_cpp():
+    """uw::Copier (include/uwip.hpp over uwip_copier_*): batches uploaded one ahead, stretched, downloaded by ticket from a
+    C++ program equal the synchronous path's bytes."""
+    _build()
+    r = subprocess.run([os.path.join(BIN, "copier_check"), "3", "270", "480", "5"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.startswith("copier ok"), r.stdout + r.stderr

@@ -162,6 +162,30 @@ def test_upright_descriptor_envelope(ctx, orc):
         assert (abs(r - truth) <= 0.01) == fine, (theta, r, truth)
 
 
+def test_matcher_ignores_descriptor_rows_past_the_count(ctx, orc):
+    """A train set with ONE keypoint whose slot still holds 2047 stale descriptors from an earlier, fuller frame (the slot
+    is refilled through uwip_features_upload with a smaller count): the matcher must report one neighbour and no second
+    one -- a dead row may not masquerade as a far second neighbour that passes the 0.8 ratio test."""
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    f = vs.Features(ctx, 2)
+    K = 2048
+    kps = np.zeros(K, vs.KP_DTYPE)
+    kps["x"] = rng.uniform(8, 632, K); kps["y"] = rng.uniform(8, 352, K)
+    desc = rng.integers(0, 256, (K, 64), dtype=np.uint8)
+    desc[:, 60] &= 0x3f; desc[:, 61:] = 0
+    for slot in (0, 1):
+        ctx.call("uwip_features_upload", f._h, slot, 360, 640, C.c_void_p(kps.ctypes.data), C.c_void_p(desc.ctypes.data), K)
+    # refill slot 0 with a single keypoint: rows 1.. of the slot are stale unless the library clears or ignores them
+    ctx.call("uwip_features_upload", f._h, 0, 360, 640, C.c_void_p(kps.ctypes.data), C.c_void_p(desc.ctypes.data), 1)
+    res = vs.match_pairs(ctx, f, f, [1], [0], 640, 480, seed=1, want_matches=True)
+    idx, dist = res["idx"].cpu().numpy()[0], res["dist"].cpu().numpy()[0]
+    eidx, edist = orc.match_knn2(desc, desc[:1])
+    assert np.array_equal(idx[:K], eidx) and np.array_equal(dist[:K], edist)
+    assert np.all(idx[:K, 0] == 0) and np.all(idx[:K, 1] == -1)
+    assert float(res["ratio"].cpu()[0]) == -2.0            # < 2 train descriptors: no good matches (B-12, guarded)
+
+
 def test_sentinels(ctx, orc):
     vs.videoWidth, vs.videoHeight = 640, 480
     flat = np.full((480, 640, 3), 90, np.uint8)                 # no keypoints -> -2.0

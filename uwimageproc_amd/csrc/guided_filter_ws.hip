@@ -135,7 +135,13 @@ struct SolveRow<NP, true> {
 // is  p = max(1 - normv(m) / B_ip, tmin)  of the 8-bit window-minimum plane m (BGDehaze.py:28-37, :52), i.e. a 256-entry
 // per-frame table, with p = 1 where the w x w window leaves the image (zero padding, :32).  Same values as
 // k_transmission writes, 1 byte instead of 8 per sample and no P planes in HBM at all.
-template <int NP, bool VEC, bool PU8>
+// C3 (TS <= 192, i.e. r >= 32: bgdehaze's r = 40 gives TS = 176): the SOLVE half of a row -- the 3x3 inversion and the
+// running column sums, about half of the kernel's float64 work -- runs on a second lane -> column mapping, three
+// adjacent OUTPUT columns per lane (lane l: strip columns r + 3l .. r + 3l + 2), so 59 of 64 lanes solve columns that are
+// written, where the accumulation mapping (four columns per lane, halo included) leaves the 20 halo lanes solving
+// nothing.  The window sums come out of the LDS prefix rows either way, so any lane can solve any column; the column
+// sums `cs` live with the solving lane.  Three column solves per wave-row instead of four: -25 % of the solve.
+template <int NP, bool VEC, bool PU8, bool C3>
 __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ guide, size_t step, size_t fs,
                                                     const int *__restrict__ gnorm, int gnorm_stride,
                                                     const double *__restrict__ P /*[F][NP][H][W]*/,
@@ -180,15 +186,35 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
 
     uint32_t gi[4][9];
     double pf[4][NP][4];
-    double cs[4][NP][4];   // running column sums of a0, a1, a2, b over this block's rows
+    constexpr int NSC = C3 ? 3 : 4;      // columns solved per lane
+    double cs[NSC][NP][4];               // running column sums of a0, a1, a2, b over this block's rows
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) gi[j][k] = 0u;
 #pragma unroll
-        for (int ip = 0; ip < NP; ++ip) {
-            pf[j][ip][0] = pf[j][ip][1] = pf[j][ip][2] = pf[j][ip][3] = 0.0;
-            cs[j][ip][0] = cs[j][ip][1] = cs[j][ip][2] = cs[j][ip][3] = 0.0;
+        for (int ip = 0; ip < NP; ++ip) pf[j][ip][0] = pf[j][ip][1] = pf[j][ip][2] = pf[j][ip][3] = 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < NSC; ++j)
+#pragma unroll
+        for (int ip = 0; ip < NP; ++ip) cs[j][ip][0] = cs[j][ip][1] = cs[j][ip][2] = cs[j][ip][3] = 0.0;
+    // the solve mapping: column j of this lane is image column sx0 + j, strip column sc0 + j
+    const int sc0 = C3 ? r + 3 * l : 4 * l, sx0 = C3 ? (int)bx * TS + 3 * l : sg.x0;
+    bool s_act[NSC], s_lo_ok[NSC];
+    int s_ah[NSC], s_al[NSC];
+#pragma unroll
+    for (int j = 0; j < NSC; ++j) {
+        if constexpr (C3) {
+            const int c = sc0 + j;
+            s_act[j] = 3 * l + j < TS && sx0 + j < W;
+            const int hh = min(c + r, 255), lo = c - r - 1;
+            s_lo_ok[j] = lo >= 0;
+            const int lc = max(lo, 0);
+            s_ah[j] = (hh & 3) * 64 + (hh >> 2);
+            s_al[j] = (lc & 3) * 64 + (lc >> 2);
+        } else {
+            s_act[j] = sg.act[j]; s_lo_ok[j] = sg.lo_ok[j]; s_ah[j] = sg.ah[j]; s_al[j] = sg.al[j];
         }
     }
 
@@ -336,60 +362,74 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
         wave_lds_fence();
 
         const double cy = count_of(y - r, y + r, H);
-#pragma unroll
-        for (int jj = 0; jj < 4; jj += 2) {
-#pragma unroll
-            for (int j2 = 0; j2 < 2; ++j2) {
-                const int j = jj + j2;
-                if (sg.act[j]) {
-                    const int x = sg.x0 + j;
-                    const double rbase = fast_rcp(cy * count_of(x - r, x + r, W));
-                    const double r1 = rdd * rbase, r2 = (rdd * rdd) * rbase;
-                    uint32_t w9[9];
-                    {
-                        const uint4 h0 = s_u4[0 * 256 + sg.ah[j]], h1 = s_u4[1 * 256 + sg.ah[j]];
-                        const uint32_t h2 = s_u1[sg.ah[j]];
-                        uint4 l0 = s_u4[0 * 256 + sg.al[j]], l1 = s_u4[1 * 256 + sg.al[j]];
-                        uint32_t l2 = s_u1[sg.al[j]];
-                        if (!sg.lo_ok[j]) { l0 = make_uint4(0, 0, 0, 0); l1 = l0; l2 = 0u; }
-                        w9[0] = h0.x - l0.x; w9[1] = h0.y - l0.y; w9[2] = h0.z - l0.z; w9[3] = h0.w - l0.w;
-                        w9[4] = h1.x - l1.x; w9[5] = h1.y - l1.y; w9[6] = h1.z - l1.z; w9[7] = h1.w - l1.w;
-                        w9[8] = h2 - l2;
-                    }
-                    const double m0 = (double)w9[0] * r1, m1 = (double)w9[1] * r1, m2 = (double)w9[2] * r1;
-                    const double s00 = (double)w9[3] * r2 - m0 * m0 + eps, s01 = (double)w9[4] * r2 - m0 * m1,
-                                 s02 = (double)w9[5] * r2 - m0 * m2, s11 = (double)w9[6] * r2 - m1 * m1 + eps,
-                                 s12 = (double)w9[7] * r2 - m1 * m2, s22 = (double)w9[8] * r2 - m2 * m2 + eps;
-                    const double k00 = s11 * s22 - s12 * s12, k01 = s02 * s12 - s01 * s22, k02 = s01 * s12 - s02 * s11;
-                    const double k11 = s00 * s22 - s02 * s02, k12 = s01 * s02 - s00 * s12, k22 = s00 * s11 - s01 * s01;
-                    const double rdet = fast_rcp(s00 * k00 + s01 * k01 + s02 * k02);
-#pragma unroll
-                    for (int ip = 0; ip < NP; ++ip) {
-                        const double2 hA = s_d2[(ip * 2 + 0) * 256 + sg.ah[j]], hB = s_d2[(ip * 2 + 1) * 256 + sg.ah[j]];
-                        double2 lA = s_d2[(ip * 2 + 0) * 256 + sg.al[j]], lB = s_d2[(ip * 2 + 1) * 256 + sg.al[j]];
-                        if (!sg.lo_ok[j]) { lA = make_double2(0.0, 0.0); lB = lA; }
-                        const double mp = (hA.x - lA.x) * rbase;
-                        const double c0 = (hA.y - lA.y) * r1 - m0 * mp, c1 = (hB.x - lB.x) * r1 - m1 * mp,
-                                     c2 = (hB.y - lB.y) * r1 - m2 * mp;
-                        const double a0 = (c0 * k00 + c1 * k01 + c2 * k02) * rdet;
-                        const double a1 = (c0 * k01 + c1 * k11 + c2 * k12) * rdet;
-                        const double a2 = (c0 * k02 + c1 * k12 + c2 * k22) * rdet;
-                        cs[j][ip][0] += a0; cs[j][ip][1] += a1; cs[j][ip][2] += a2;
-                        cs[j][ip][3] += mp - a0 * m0 - a1 * m1 - a2 * m2;
-                    }
-                }
+        auto solve_col = [&](int j) {
+            const int x = sx0 + j;
+            const double rbase = fast_rcp(cy * count_of(x - r, x + r, W));
+            const double r1 = rdd * rbase, r2 = (rdd * rdd) * rbase;
+            uint32_t w9[9];
+            {
+                const uint4 h0 = s_u4[0 * 256 + s_ah[j]], h1 = s_u4[1 * 256 + s_ah[j]];
+                const uint32_t h2 = s_u1[s_ah[j]];
+                uint4 l0 = s_u4[0 * 256 + s_al[j]], l1 = s_u4[1 * 256 + s_al[j]];
+                uint32_t l2 = s_u1[s_al[j]];
+                if (!s_lo_ok[j]) { l0 = make_uint4(0, 0, 0, 0); l1 = l0; l2 = 0u; }
+                w9[0] = h0.x - l0.x; w9[1] = h0.y - l0.y; w9[2] = h0.z - l0.z; w9[3] = h0.w - l0.w;
+                w9[4] = h1.x - l1.x; w9[5] = h1.y - l1.y; w9[6] = h1.z - l1.z; w9[7] = h1.w - l1.w;
+                w9[8] = h2 - l2;
             }
-            const size_t i = (size_t)y * W + sg.x0 + jj;
+            const double m0 = (double)w9[0] * r1, m1 = (double)w9[1] * r1, m2 = (double)w9[2] * r1;
+            const double s00 = (double)w9[3] * r2 - m0 * m0 + eps, s01 = (double)w9[4] * r2 - m0 * m1,
+                         s02 = (double)w9[5] * r2 - m0 * m2, s11 = (double)w9[6] * r2 - m1 * m1 + eps,
+                         s12 = (double)w9[7] * r2 - m1 * m2, s22 = (double)w9[8] * r2 - m2 * m2 + eps;
+            const double k00 = s11 * s22 - s12 * s12, k01 = s02 * s12 - s01 * s22, k02 = s01 * s12 - s02 * s11;
+            const double k11 = s00 * s22 - s02 * s02, k12 = s01 * s02 - s00 * s12, k22 = s00 * s11 - s01 * s01;
+            const double rdet = fast_rcp(s00 * k00 + s01 * k01 + s02 * k02);
 #pragma unroll
             for (int ip = 0; ip < NP; ++ip) {
-                double *o = AB + ((size_t)zg * NP + ip) * 4 * n + i;
+                const double2 hA = s_d2[(ip * 2 + 0) * 256 + s_ah[j]], hB = s_d2[(ip * 2 + 1) * 256 + s_ah[j]];
+                double2 lA = s_d2[(ip * 2 + 0) * 256 + s_al[j]], lB = s_d2[(ip * 2 + 1) * 256 + s_al[j]];
+                if (!s_lo_ok[j]) { lA = make_double2(0.0, 0.0); lB = lA; }
+                const double mp = (hA.x - lA.x) * rbase;
+                const double c0 = (hA.y - lA.y) * r1 - m0 * mp, c1 = (hB.x - lB.x) * r1 - m1 * mp,
+                             c2 = (hB.y - lB.y) * r1 - m2 * mp;
+                const double a0 = (c0 * k00 + c1 * k01 + c2 * k02) * rdet;
+                const double a1 = (c0 * k01 + c1 * k11 + c2 * k12) * rdet;
+                const double a2 = (c0 * k02 + c1 * k12 + c2 * k22) * rdet;
+                cs[j][ip][0] += a0; cs[j][ip][1] += a1; cs[j][ip][2] += a2;
+                cs[j][ip][3] += mp - a0 * m0 - a1 * m1 - a2 * m2;
+            }
+        };
+        if constexpr (C3) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (VEC) {
-                        if (sg.act[jj]) *reinterpret_cast<double2 *>(o + (size_t)q * n) = make_double2(cs[jj][ip][q], cs[jj + 1][ip][q]);
-                    } else {
-                        if (sg.act[jj]) o[(size_t)q * n] = cs[jj][ip][q];
-                        if (sg.act[jj + 1]) o[(size_t)q * n + 1] = cs[jj + 1][ip][q];
+            for (int j = 0; j < 3; ++j) {
+                if (s_act[j]) solve_col(j);
+                const size_t i = (size_t)y * W + sx0 + j;
+#pragma unroll
+                for (int ip = 0; ip < NP; ++ip) {
+                    double *o = AB + ((size_t)zg * NP + ip) * 4 * n + i;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (s_act[j]) o[(size_t)q * n] = cs[j][ip][q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int jj = 0; jj < 4; jj += 2) {
+#pragma unroll
+                for (int j2 = 0; j2 < 2; ++j2)
+                    if (s_act[jj + j2]) solve_col(jj + j2);
+                const size_t i = (size_t)y * W + sg.x0 + jj;
+#pragma unroll
+                for (int ip = 0; ip < NP; ++ip) {
+                    double *o = AB + ((size_t)zg * NP + ip) * 4 * n + i;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (VEC) {
+                            if (sg.act[jj]) *reinterpret_cast<double2 *>(o + (size_t)q * n) = make_double2(cs[jj][ip][q], cs[jj + 1][ip][q]);
+                        } else {
+                            if (sg.act[jj]) o[(size_t)q * n] = cs[jj][ip][q];
+                            if (sg.act[jj + 1]) o[(size_t)q * n + 1] = cs[jj + 1][ip][q];
+                        }
                     }
                 }
             }
@@ -625,9 +665,10 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
     const bool split = !pu8 && np == 2 && env_split && atoi(env_split) > 0;   // two one-plane solves instead of a fused one
     const int knp = split ? 1 : np;
     const unsigned zs = (unsigned)F * (np / knp);
-    const void *ksolve = pu8 ? (const void *)k_gf_ws_solve<2, true, true>
-                       : knp == 2 ? (vec ? (const void *)k_gf_ws_solve<2, true, false> : (const void *)k_gf_ws_solve<2, false, false>)
-                                  : (vec ? (const void *)k_gf_ws_solve<1, true, false> : (const void *)k_gf_ws_solve<1, false, false>);
+    // (occupancy query only: the 3-column and 4-column solve mappings differ by a few registers, both one wave per SIMD)
+    const void *ksolve = pu8 ? (const void *)k_gf_ws_solve<2, true, true, true>
+                       : knp == 2 ? (vec ? (const void *)k_gf_ws_solve<2, true, false, true> : (const void *)k_gf_ws_solve<2, false, false, true>)
+                                  : (vec ? (const void *)k_gf_ws_solve<1, true, false, true> : (const void *)k_gf_ws_solve<1, false, false, true>);
     // solve: every row chunk re-reads 2r warm-up rows, so use as few chunks as keep the chip full, preferring a whole
     // number of "rounds" of resident waves.  A chunk is at least 2r+1 rows (k_gf_ws_final relies on it).
     int c = 1;
@@ -655,13 +696,13 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
         const int fdiv = np / knp;
         const uwip_gf_pu8 none{};
         if (pu8) {
-            k_gf_ws_solve<2, true, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, *pu8);
+            { if (TS <= 192) k_gf_ws_solve<2, true, true, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, *pu8); else k_gf_ws_solve<2, true, true, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, *pu8); }
         } else if (knp == 2) {
-            if (vec) k_gf_ws_solve<2, true, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none);
-            else k_gf_ws_solve<2, false, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none);
+            if (vec) { if (TS <= 192) k_gf_ws_solve<2, true, false, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); else k_gf_ws_solve<2, true, false, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); }
+            else { if (TS <= 192) k_gf_ws_solve<2, false, false, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); else k_gf_ws_solve<2, false, false, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); }
         } else {
-            if (vec) k_gf_ws_solve<1, true, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none);
-            else k_gf_ws_solve<1, false, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none);
+            if (vec) { if (TS <= 192) k_gf_ws_solve<1, true, false, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); else k_gf_ws_solve<1, true, false, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); }
+            else { if (TS <= 192) k_gf_ws_solve<1, false, false, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); else k_gf_ws_solve<1, false, false, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); }
         }
     }
     {

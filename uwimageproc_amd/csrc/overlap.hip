@@ -914,11 +914,16 @@ __global__ __launch_bounds__(64 * NW) void k_ov_match(const int8_t *__restrict__
         // (|b| + 512) << 11 | t for this lane's four train columns of the tile (a dead column, t >= nt, keeps every key
         // above any live key); requested before the MFMAs so that the popcount loads hide behind them.  The query's own
         // popcount is the same for all candidates of a row, so it is added when the result is written, not per candidate.
+        // A dead column's key must not depend on what its descriptor row holds (k_ov_describe and uwip_features_upload
+        // zero the rows past the count, but nothing else guarantees it): its dot product is multiplied by 0 instead of
+        // -4096, at no cost in the epilogue (the multiplier of the v_mad_i32_i24 is a register either way).
         uint32_t tb[4];
+        int mf[4];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const int t = t0 + tt * 16 + row;
             tb[tt] = t < nt ? ((((uint32_t)tpop[(size_t)ft * MAXKP + t] + 512u) << 11) | (uint32_t)t) : 0x7ff00000u;
+            mf[tt] = t < nt ? -4096 : 0;
         }
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
@@ -937,7 +942,7 @@ __global__ __launch_bounds__(64 * NW) void k_ov_match(const int8_t *__restrict__
             for (int u = 0; u < QT; ++u)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    top2_push(b0[u][r], b1[u][r], (uint32_t)(__mul24(acc[u][r], -4096) + (int)tb[tt]));
+                    top2_push(b0[u][r], b1[u][r], (uint32_t)(__mul24(acc[u][r], mf[tt]) + (int)tb[tt]));
         }
         if (t0 + 64 < nt) {
             park((it & 1) ? bufA : bufB);        // tile t+1: its buffer was last read in iteration t-1, before that barrier
