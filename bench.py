@@ -572,7 +572,7 @@ def fourk_leg(args, dev_index, dev, rank, world):
     HBM-resident and 2 steps through host buffers, then config 5's paced 4K@60 stream (a short one: 2 s) on every rank."""
     from uwimageproc_amd import sharding
     H, W, F, S = 2160, 3840, 64, max(1, args.streams)
-    rig = Rig(dev_index, dev, F, H, W, S, 4321 + 1000 * rank)
+    rig = Rig(dev_index, dev, F, H, W, S, 1234 + 1000 * rank)        # the same scene as --config 4k
     steps = 2
     dt = timed(rig, world, steps, 1, host=False)
     out = {"workload": f"full pipe on {W}x{H} uchar3 frames, {F} per GPU and step", "steps": steps,
