@@ -71,12 +71,14 @@ def parse():
 
 
 def synth_frames(n, H, W, seed0):
-    """n consecutive frames of the synthetic underwater stream, generated on the host cores in parallel"""
+    """n consecutive frames of the synthetic underwater stream (one corner-rich scene, consecutive frames related
+    by a known homography -- translation 3 % of the width + yaw <= 1 degree + zoom <= 1 % per frame, synth.uw_stream_motion),
+    generated on the host cores in parallel"""
     from concurrent.futures import ThreadPoolExecutor
     from uwimageproc_amd import synth
-    chunk = 8
-    with ThreadPoolExecutor(max_workers=8) as ex:
-        parts = list(ex.map(lambda k: synth.uw_stream(k * chunk, min(chunk, n - k * chunk), H, W, seed0=seed0), range((n + chunk - 1) // chunk)))
+    chunk = 4
+    with ThreadPoolExecutor(max_workers=min(16, len(os.sched_getaffinity(0)))) as ex:
+        parts = list(ex.map(lambda k: synth.uw_stream_motion(k * chunk, min(chunk, n - k * chunk), H, W, seed0=seed0), range((n + chunk - 1) // chunk)))
     return np.concatenate(parts, axis=0)
 
 
@@ -150,7 +152,7 @@ def cpu_baseline(H, W):
     select = uwip_lib().uwip_aclahe_select          # pure host function (MINPACK / spline restatement): CPU code on both sides
 
     def one_frame(idx, timing=None):
-        img = synth.uw_stream(idx, 2, H, W)
+        img = synth.uw_stream_motion(idx, 2, H, W)
         t = [time.perf_counter()]
         out, _ = orc.dehaze(img[1], 15, full=True, guard_s=True); t.append(time.perf_counter())
         st, _ = orc.histretch(out, "RGB")

@@ -147,6 +147,20 @@ def test_overlap_under_rotation_and_zoom(ctx, orc, theta, scale):
     assert info[3] >= 40                      # inliers: a comfortable margin, not a lucky fit
 
 
+def test_bench_stream_consecutive_frames_vs_truth(ctx, orc):
+    """The bench's synthetic stream (synth.uw_stream_motion: translation + yaw <= 1 degree + zoom <= 1 % per frame,
+    accumulating): overlap of frames 1 and 3 steps apart against the exact homography of the generator."""
+    vs.videoWidth, vs.videoHeight = 640, 480
+    fr = synth.uw_stream_motion(20, 4, 1080, 1920)
+    kf = vs.keyframe(ctx, _dev(fr[0]))
+    for j in (1, 3):
+        H = synth.uw_stream_motion_H(20, 20 + j, 1080, 1920)
+        truth, _ = orc.overlapArea(synth.to_working_homography(H, 1920), 640, 480)
+        r = vs.calcOverlap(ctx, kf, _dev(fr[j]), seed=1)
+        er, _, _ = orc.calcOverlap(fr[0], fr[j], 640, 480, seed=1)
+        assert abs(r - er) <= 1e-6 and abs(r - truth) <= 0.01, (j, r, truth)
+
+
 def test_upright_descriptor_envelope(ctx, orc):
     """What the orientation buys: with UWIP_OVERLAP_UPRIGHT (round 2's descriptor) the device still equals the oracle bit
     for bit, and both lose the overlap beyond ~20 degrees of yaw."""

@@ -155,3 +155,54 @@ def to_working_homography(H_full: np.ndarray, cols: int, target_w: int = 640) ->
     f = target_w / float(cols)
     S = np.array([[f, 0.0, 0.5 * f - 0.5], [0.0, f, 0.5 * f - 0.5], [0.0, 0.0, 1.0]])
     return S @ H_full @ np.linalg.inv(S)
+
+
+def _motion_state(k: int, cols: int, step_frac: float, seed0: int):
+    """Cumulative camera pose of frame k of `uw_stream_motion`: (theta_deg, scale, tx, ty).  Frame j adds a translation of
+    step_frac * cols (and a third of it downwards), a yaw drawn uniformly from [-1, 1] degrees and a zoom factor from
+    [0.99, 1.01] ("translation 2-4 % of width + rotation <= 1 deg + scale <= 1 %"), each seeded by j alone, so
+    any frame can be generated without its predecessors."""
+    th, sc = 0.0, 1.0
+    for j in range(1, k + 1):
+        r = np.random.default_rng(seed0 * 7919 + 104729 + j)
+        th += float(r.uniform(-1.0, 1.0))
+        sc *= 1.0 + float(r.uniform(-0.01, 0.01))
+    sx = step_frac * cols
+    return th, sc, k * sx, k * sx / 3.0
+
+
+def uw_stream_motion(first: int, frames: int, rows: int, cols: int, step_frac: float = 0.03, seed0: int = 1234):
+    """SURVEY 8(d)'s synthetic stream in full: consecutive frames of one corner-rich scene related by a KNOWN homography --
+    translation, yaw <= 1 degree and zoom <= 1 % per frame (accumulating like a real track) -- sampled bilinearly from a
+    larger texture, with the underwater colour cast and per-frame noise of `uw_stream`.  `uw_stream_motion_H` gives the
+    exact homography between two frames."""
+    total = first + frames
+    margin = int(0.2 * max(rows, cols))
+    sx = step_frac * cols
+    tex = _texture(seed0, rows + int(sx / 3.0 * (total + 1)) + 2 * margin, cols + int(sx * (total + 1)) + 2 * margin)
+    yy, xx = np.meshgrid(np.arange(rows, dtype=np.float64), np.arange(cols, dtype=np.float64), indexing="ij")
+    cx, cy = (cols - 1) / 2.0, (rows - 1) / 2.0
+    out = np.empty((frames, rows, cols, 3), np.uint8)
+    for i in range(frames):
+        k = first + i
+        th, sc, tx, ty = _motion_state(k, cols, step_frac, seed0)
+        A = _affine(th, sc, tx, ty, cx, cy)
+        X = A[0, 0] * xx + A[0, 1] * yy + A[0, 2] + margin
+        Y = A[1, 0] * xx + A[1, 1] * yy + A[1, 2] + margin
+        win = _sample_bilinear(tex, X, Y) * 200.0
+        rng = np.random.default_rng(seed0 + k)
+        f = np.empty((rows, cols, 3), np.float32)
+        f[..., 0] = win * 1.0 + 50.0
+        f[..., 1] = win * 0.8 + 35.0
+        f[..., 2] = win * 0.35 + 10.0
+        f += rng.integers(-4, 5, size=f.shape).astype(np.float32)
+        out[i] = np.clip(np.rint(f), 0, 255).astype(np.uint8)
+    return out
+
+
+def uw_stream_motion_H(key: int, cur: int, rows: int, cols: int, step_frac: float = 0.03, seed0: int = 1234) -> np.ndarray:
+    """Exact 3x3 homography taking pixel coordinates of frame `cur` of `uw_stream_motion` to those of frame `key`."""
+    cx, cy = (cols - 1) / 2.0, (rows - 1) / 2.0
+    Ak = _affine(*_motion_state(key, cols, step_frac, seed0), cx, cy)
+    Ac = _affine(*_motion_state(cur, cols, step_frac, seed0), cx, cy)
+    return np.linalg.inv(Ak) @ Ac
