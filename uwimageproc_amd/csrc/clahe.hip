@@ -619,17 +619,27 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
         constexpr int MS = SWEEP_SPREAD / (SWEEP_THREADS / 64);
         auto pix_of = [&](int t) { return (t / MS) * (64 * SWEEP_SPREAD) + (tid & 63) * SWEEP_SPREAD + (tid >> 6) + (SWEEP_THREADS / 64) * (t % MS); };
         static_assert(MS == 1, "consecutive pixels of a thread are SWEEP_THREADS apart");
-        int p = pix_of(0);
-        if (p < npix) { locate(p, xn, yn); vnext = pix_at(xn, yn); }
+        // Whole groups of SWEEP_THREADS pixels go by the spread mapping (a permutation of the group); the remainder of the
+        // cell (npix mod 512 pixels) is taken contiguously, one pixel per thread from thread 0 on, so that only
+        // ceil(rem / 64) waves run the last round instead of all eight with a few lanes each (a 61 x 34 cell of the 32 x 32
+        // grid has 4 whole groups + 26 pixels: 5 rounds for every wave became 4 + one wave's).
+        const int nfull = npix / SWEEP_THREADS, rem = npix - nfull * SWEEP_THREADS;
+        const int ntot = nfull + (tid < rem ? 1 : 0);
+        int t = 0;
+        if (ntot > 0) { locate(nfull > 0 ? pix_of(0) : tid, xn, yn); vnext = pix_at(xn, yn); }
         // a thread's next pixel is SWEEP_THREADS further along the cell: step (x, y) instead of dividing again
         const int dq = SWEEP_THREADS / w, dr = SWEEP_THREADS - dq * w;     // wave-uniform
-        for (; p < npix;) {
+        for (; t < ntot;) {
             const int x = xn, y = yn;
             const uint32_t v = vnext;
-            p += SWEEP_THREADS;
-            if (p < npix) {
-                xn += dr; yn += dq;
-                if (xn >= ci.x1) { xn -= w; yn++; }
+            ++t;
+            if (t < ntot) {
+                if (t < nfull) {
+                    xn += dr; yn += dq;
+                    if (xn >= ci.x1) { xn -= w; yn++; }
+                } else {
+                    locate(nfull * SWEEP_THREADS + tid, xn, yn);      // the remainder pixel
+                }
                 vnext = pix_at(xn, yn);
             }
             const float txf = (float)x * inv_tw - 0.5f;
