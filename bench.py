@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--no-host-buffers", dest="host_buffers", action="store_false",
                     help="skip the upload/download-inclusive variant (timed on every rank after the main region)")
     ap.add_argument("--no-4k", dest="fourk", action="store_false",
-                    help="skip the short 3840x2160 leg of the default line (configs 3 / 5: 2 steps + a 2 s paced 4K@60 stream)")
+                    help="skip the short 3840x2160 leg of the default line (configs 3 / 5: 6 steps + a 2 s paced 4K@60 stream)")
     ap.add_argument("--no-pin", dest="pin", action="store_false",
                     help="do not restrict the rank to the CPUs of its GPU's NUMA node")
     a = ap.parse_args()
@@ -572,12 +572,12 @@ def host_leg(rig, world, steps):
 
 
 def fourk_leg(args, dev_index, dev, rank, world):
-    """BASELINE configs 3 / 5 inside the default line: the same pipe on 3840x2160 frames (64 per GPU and step), 2 steps
-    HBM-resident and 2 steps through host buffers, then config 5's paced 4K@60 stream (a short one: 2 s) on every rank."""
+    """BASELINE configs 3 / 5 inside the default line: the same pipe on 3840x2160 frames (64 per GPU and step), 6 steps
+    HBM-resident and 6 steps through host buffers, then config 5's paced 4K@60 stream (a short one: 2 s) on every rank."""
     from uwimageproc_amd import sharding
     H, W, F, S = 2160, 3840, 64, max(1, args.streams)
     rig = Rig(dev_index, dev, F, H, W, S, 1234 + 1000 * rank)        # the same scene as --config 4k
-    steps = 2
+    steps = 6
     dt = timed(rig, world, steps, 1, host=False)
     out = {"workload": f"full pipe on {W}x{H} uchar3 frames, {F} per GPU and step", "steps": steps,
            "value": world * F * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3}
