@@ -53,3 +53,20 @@ def test_no_cpu_fallback_without_device():
         pytest.skip("a HIP device is present")
     with pytest.raises(uw.UwipError):
         uw.Context(0)
+    with pytest.raises(uw.UwipError):
+        uw.Copier(0)                     # the copy engine needs a device as well: no host-only fallback
+
+
+def test_copier_argument_checks_without_device():
+    """uwip_copier_* reject null handles / null out-pointers with UWIP_ERR_INVALID instead of touching them."""
+    import uwimageproc_amd._native as nat
+    l = nat.lib()
+    t = C.c_uint64(7)
+    d = C.c_int(5)
+    assert l.uwip_copier_create(0, None) == nat.UWIP_ERR_INVALID
+    assert l.uwip_copier_upload(None, None, None, None, 16, C.byref(t)) == nat.UWIP_ERR_INVALID
+    assert l.uwip_copier_download(None, None, None, None, 16, C.byref(t)) == nat.UWIP_ERR_INVALID
+    assert l.uwip_copier_wait(None, 0) == nat.UWIP_ERR_INVALID
+    assert l.uwip_copier_query(None, 0, C.byref(d)) == nat.UWIP_ERR_INVALID
+    assert l.uwip_copier_destroy(None) == nat.UWIP_OK
+    assert l.uwip_copier_last_error(None) == b"null copier"
