@@ -93,6 +93,25 @@ def test_guided_filter_vs_oracle(ctx, shape, r, eps):
     assert np.abs(q - qo).max() <= TOL
 
 
+@pytest.mark.parametrize("shape,r", [((200, 1100), 40), ((170, 516), 12), ((330, 1920), 40)])
+def test_guided_filter_two_waves_per_strip(ctx, monkeypatch, shape, r):
+    """UWIP_GF_NW=2 (two waves share a 512-column strip, the scans meet in LDS): windows inside one half, windows that
+    straddle the halves and the image's right edge inside the second half -- against the oracle and the one-wave form;
+    then the dehaze chain through RC_correction, whose first filter is the fused two-plane, 8-bit-p form of the kernel."""
+    rng = np.random.default_rng(8)
+    guide = synth.uw_frame(3, *shape)
+    p = rng.random(shape)
+    qo = dz.guided_filter(dz.normalize_input(guide), p, r, 1e-3)
+    monkeypatch.setenv("UWIP_GF_NW", "2")
+    q2 = bg.guided_filter(ctx, _dev(guide), _dev(p), r, 1e-3).cpu().numpy()[0]
+    res2 = bg.dehaze(ctx, _dev(guide), 15, full=False, want_float=True)["float"].cpu().numpy()[0] if r == 40 else None
+    monkeypatch.setenv("UWIP_GF_NW", "1")
+    q1 = bg.guided_filter(ctx, _dev(guide), _dev(p), r, 1e-3).cpu().numpy()[0]
+    assert np.abs(q2 - qo).max() <= TOL and np.abs(q1 - qo).max() <= TOL
+    if res2 is not None:
+        assert np.abs(res2 - dz.RC_correction(dz.normalize_input(guide), 15)).max() <= TOL
+
+
 def test_guided_filter_rejects_large_radius(ctx):
     import uwimageproc_amd as uw
     guide = synth.uw_frame(7, 210, 230)

@@ -87,22 +87,25 @@ struct StripGeom {
     int l, x0;           // lane, image column of the lane's first column
     bool in[4];          // column inside the image
     bool act[4];         // column is an output column of this strip
-    int ah[4], al[4];    // LDS slots (j * 64 + lane) of G[c + r] and G[c - r - 1]
+    int ah[4], al[4];    // LDS slots (j * 64 + lane) of G[c + r] and G[c - r - 1] inside the row of the wave that holds them
+    int ahw[4], alw[4];  // ... and that wave (a strip of `nw` waves is 256 nw columns wide; nw = 1: always 0)
     bool lo_ok[4];       // c - r - 1 >= 0 (else G = 0)
-    __device__ __forceinline__ void init(int bx, int TS, int r, int W)
+    __device__ __forceinline__ void init(int bx, int TS, int r, int W, int nw = 1)
     {
         l = threadIdx.x & 63;
-        x0 = bx * TS - r + 4 * l;
+        const int L = nw > 1 ? (int)threadIdx.x : l;          // lane index inside the strip
+        x0 = bx * TS - r + 4 * L;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int c = 4 * l + j, x = x0 + j;
+            const int c = 4 * L + j, x = x0 + j;
             in[j] = x >= 0 && x < W;
             act[j] = c >= r && c < r + TS && x < W;
-            const int h = min(c + r, 255), lo = c - r - 1;
+            const int h = min(c + r, 256 * nw - 1), lo = c - r - 1;
             lo_ok[j] = lo >= 0;
             const int lc = max(lo, 0);
-            ah[j] = (h & 3) * 64 + (h >> 2);
-            al[j] = (lc & 3) * 64 + (lc >> 2);
+            ahw[j] = h >> 8; alw[j] = lc >> 8;
+            ah[j] = (h & 3) * 64 + ((h & 255) >> 2);
+            al[j] = (lc & 3) * 64 + ((lc & 255) >> 2);
         }
     }
 };
@@ -141,8 +144,12 @@ struct SolveRow<NP, true> {
 // written, where the accumulation mapping (four columns per lane, halo included) leaves the 20 halo lanes solving
 // nothing.  The window sums come out of the LDS prefix rows either way, so any lane can solve any column; the column
 // sums `cs` live with the solving lane.  Three column solves per wave-row instead of four: -25 % of the solve.
-template <int NP, bool VEC, bool PU8, bool C3>
-__global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ guide, size_t step, size_t fs,
+// NW = 2: TWO waves share a strip of 512 columns (432 outputs + the same 2 x 40 halo columns), each accumulating and
+// scanning its own 256; the scans meet in LDS -- a window that straddles the two halves adds the left wave's row total --
+// behind one workgroup barrier per phase.  Useful columns per lane-column rise from 176 / 256 to 432 / 512: at 1920
+// columns 5 strips x 512 instead of 11 x 256 (-9 % of all work), at 3840 columns 9 x 512 instead of 22 x 256 (-18 %).
+template <int NP, bool VEC, bool PU8, bool C3, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gf_ws_solve(const uint8_t *__restrict__ guide, size_t step, size_t fs,
                                                     const int *__restrict__ gnorm, int gnorm_stride,
                                                     const double *__restrict__ P /*[F][NP][H][W]*/,
                                                     double *__restrict__ AB /*[F*NP][4][H][W]: column prefix sums of a, b*/,
@@ -151,14 +158,20 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
 {
 #pragma clang fp contract(fast)
     static_assert(!PU8 || VEC, "the 8-bit p source needs the aligned path");
-    __shared__ uint4 s_u4[2 * 4 * 64];
-    __shared__ uint32_t s_u1[4 * 64];
-    __shared__ double2 s_d2[NP * 2 * 4 * 64];
+    static_assert(NW == 1 || (NW == 2 && !C3), "one or two waves per strip; the 3-column solve mapping is the one-wave form");
+    __shared__ uint4 s_u4[NW * 2 * 4 * 64];
+    __shared__ uint32_t s_u1[NW * 4 * 64];
+    __shared__ double2 s_d2[NW * NP * 2 * 4 * 64];
+    __shared__ uint32_t s_tu[NW][12];          // row totals of a wave's nine integer planes
+    __shared__ double s_td[NW][NP * 4];        // ... and of its 4 NP float64 planes
     __shared__ double s_ptab[PU8 ? NP * 256 : 1];
     unsigned bx, by, bz;
     if (!xcd_decode(nb.x, nb.y, nb.z, bx, by, bz)) return;
     StripGeom sg;
-    sg.init(bx, TS, r, W);
+    sg.init(bx, TS, r, W, NW);
+    const int wv = NW > 1 ? (int)(threadIdx.x >> 6) : 0;
+    // hand-over between the phases of a row: the LDS rows are private to the wave (NW = 1) or shared by the block
+    auto sync = [&]() { if constexpr (NW > 1) __syncthreads(); else wave_lds_fence(); };
     // bz counts groups of NP p-planes; fdiv of them share a frame (fdiv = np / NP)
     const int l = sg.l, zg = bz, f = zg / fdiv;
     const size_t n = (size_t)H * W;
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
     double p_out = 0.0;         // PU8: p where the window leaves the image
     bool cin[4] = {true, true, true, true};
     if (PU8) {
-        for (int idx = l; idx < NP * 256; idx += 64) {
+        for (int idx = (int)threadIdx.x; idx < NP * 256; idx += 64 * NW) {
             const int ip = idx >> 8, v = idx & 255;
             const double B = pu8.sc[(size_t)f * pu8.sc_stride + pu8.b_off + ip];
             const double q = ((double)(v - mn) / (double)(mx - mn)) / B;
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
             const int x = sg.x0 + j;
             cin[j] = (x - pu8.pad >= 0) && (x - pu8.pad + pu8.w <= W);
         }
-        wave_lds_fence();
+        sync();
     }
 
     uint32_t gi[4][9];
@@ -202,7 +215,7 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
     // the solve mapping: column j of this lane is image column sx0 + j, strip column sc0 + j
     const int sc0 = C3 ? r + 3 * l : 4 * l, sx0 = C3 ? (int)bx * TS + 3 * l : sg.x0;
     bool s_act[NSC], s_lo_ok[NSC];
-    int s_ah[NSC], s_al[NSC];
+    int s_ah[NSC], s_al[NSC], s_ahw[NSC], s_alw[NSC];
 #pragma unroll
     for (int j = 0; j < NSC; ++j) {
         if constexpr (C3) {
@@ -213,8 +226,10 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
             const int lc = max(lo, 0);
             s_ah[j] = (hh & 3) * 64 + (hh >> 2);
             s_al[j] = (lc & 3) * 64 + (lc >> 2);
+            s_ahw[j] = 0; s_alw[j] = 0;
         } else {
             s_act[j] = sg.act[j]; s_lo_ok[j] = sg.lo_ok[j]; s_ah[j] = sg.ah[j]; s_al[j] = sg.al[j];
+            s_ahw[j] = sg.ahw[j]; s_alw[j] = sg.alw[j];
         }
     }
 
@@ -338,9 +353,13 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s_u4[(0 * 4 + j) * 64 + l] = make_uint4(G[0][j], G[1][j], G[2][j], G[3][j]);
-                s_u4[(1 * 4 + j) * 64 + l] = make_uint4(G[4][j], G[5][j], G[6][j], G[7][j]);
-                s_u1[j * 64 + l] = G[8][j];
+                s_u4[wv * 512 + (0 * 4 + j) * 64 + l] = make_uint4(G[0][j], G[1][j], G[2][j], G[3][j]);
+                s_u4[wv * 512 + (1 * 4 + j) * 64 + l] = make_uint4(G[4][j], G[5][j], G[6][j], G[7][j]);
+                s_u1[wv * 256 + j * 64 + l] = G[8][j];
+            }
+            if (NW > 1 && l == 63) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) s_tu[wv][k] = G[k][3];
             }
         }
         // ---- and of the 4 NP float64 planes
@@ -355,11 +374,15 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s_d2[((ip * 2 + 0) * 4 + j) * 64 + l] = make_double2(D[0][j], D[1][j]);
-                s_d2[((ip * 2 + 1) * 4 + j) * 64 + l] = make_double2(D[2][j], D[3][j]);
+                s_d2[wv * (NP * 512) + ((ip * 2 + 0) * 4 + j) * 64 + l] = make_double2(D[0][j], D[1][j]);
+                s_d2[wv * (NP * 512) + ((ip * 2 + 1) * 4 + j) * 64 + l] = make_double2(D[2][j], D[3][j]);
+            }
+            if (NW > 1 && l == 63) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s_td[wv][ip * 4 + k] = D[k][3];
             }
         }
-        wave_lds_fence();
+        sync();
 
         const double cy = count_of(y - r, y + r, H);
         auto solve_col = [&](int j) {
@@ -368,11 +391,16 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
             const double r1 = rdd * rbase, r2 = (rdd * rdd) * rbase;
             uint32_t w9[9];
             {
-                const uint4 h0 = s_u4[0 * 256 + s_ah[j]], h1 = s_u4[1 * 256 + s_ah[j]];
-                const uint32_t h2 = s_u1[s_ah[j]];
-                uint4 l0 = s_u4[0 * 256 + s_al[j]], l1 = s_u4[1 * 256 + s_al[j]];
-                uint32_t l2 = s_u1[s_al[j]];
+                const uint4 h0 = s_u4[s_ahw[j] * 512 + 0 * 256 + s_ah[j]], h1 = s_u4[s_ahw[j] * 512 + 1 * 256 + s_ah[j]];
+                const uint32_t h2 = s_u1[s_ahw[j] * 256 + s_ah[j]];
+                uint4 l0 = s_u4[s_alw[j] * 512 + 0 * 256 + s_al[j]], l1 = s_u4[s_alw[j] * 512 + 1 * 256 + s_al[j]];
+                uint32_t l2 = s_u1[s_alw[j] * 256 + s_al[j]];
                 if (!s_lo_ok[j]) { l0 = make_uint4(0, 0, 0, 0); l1 = l0; l2 = 0u; }
+                if (NW > 1 && s_ahw[j] != s_alw[j]) {      // the window straddles the two halves: + the left wave's row totals
+                    l0.x -= s_tu[0][0]; l0.y -= s_tu[0][1]; l0.z -= s_tu[0][2]; l0.w -= s_tu[0][3];
+                    l1.x -= s_tu[0][4]; l1.y -= s_tu[0][5]; l1.z -= s_tu[0][6]; l1.w -= s_tu[0][7];
+                    l2 -= s_tu[0][8];
+                }
                 w9[0] = h0.x - l0.x; w9[1] = h0.y - l0.y; w9[2] = h0.z - l0.z; w9[3] = h0.w - l0.w;
                 w9[4] = h1.x - l1.x; w9[5] = h1.y - l1.y; w9[6] = h1.z - l1.z; w9[7] = h1.w - l1.w;
                 w9[8] = h2 - l2;
@@ -386,9 +414,14 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
             const double rdet = fast_rcp(s00 * k00 + s01 * k01 + s02 * k02);
 #pragma unroll
             for (int ip = 0; ip < NP; ++ip) {
-                const double2 hA = s_d2[(ip * 2 + 0) * 256 + s_ah[j]], hB = s_d2[(ip * 2 + 1) * 256 + s_ah[j]];
-                double2 lA = s_d2[(ip * 2 + 0) * 256 + s_al[j]], lB = s_d2[(ip * 2 + 1) * 256 + s_al[j]];
+                const double2 hA = s_d2[s_ahw[j] * (NP * 512) + (ip * 2 + 0) * 256 + s_ah[j]],
+                              hB = s_d2[s_ahw[j] * (NP * 512) + (ip * 2 + 1) * 256 + s_ah[j]];
+                double2 lA = s_d2[s_alw[j] * (NP * 512) + (ip * 2 + 0) * 256 + s_al[j]],
+                        lB = s_d2[s_alw[j] * (NP * 512) + (ip * 2 + 1) * 256 + s_al[j]];
                 if (!s_lo_ok[j]) { lA = make_double2(0.0, 0.0); lB = lA; }
+                if (NW > 1 && s_ahw[j] != s_alw[j]) {
+                    lA.x -= s_td[0][ip * 4 + 0]; lA.y -= s_td[0][ip * 4 + 1]; lB.x -= s_td[0][ip * 4 + 2]; lB.y -= s_td[0][ip * 4 + 3];
+                }
                 const double mp = (hA.x - lA.x) * rbase;
                 const double c0 = (hA.y - lA.y) * r1 - m0 * mp, c1 = (hB.x - lB.x) * r1 - m1 * mp,
                              c2 = (hB.y - lB.y) * r1 - m2 * mp;
@@ -434,7 +467,7 @@ __global__ __launch_bounds__(64) void k_gf_ws_solve(const uint8_t *__restrict__ 
                 }
             }
         }
-        wave_lds_fence();
+        sync();
     }
 }
 
@@ -666,9 +699,20 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
     const int knp = split ? 1 : np;
     const unsigned zs = (unsigned)F * (np / knp);
     // (occupancy query only: the 3-column and 4-column solve mappings differ by a few registers, both one wave per SIMD)
-    const void *ksolve = pu8 ? (const void *)k_gf_ws_solve<2, true, true, true>
-                       : knp == 2 ? (vec ? (const void *)k_gf_ws_solve<2, true, false, true> : (const void *)k_gf_ws_solve<2, false, false, true>)
-                                  : (vec ? (const void *)k_gf_ws_solve<1, true, false, true> : (const void *)k_gf_ws_solve<1, false, false, true>);
+    const void *ksolve = pu8 ? (const void *)k_gf_ws_solve<2, true, true, true, 1>
+                       : knp == 2 ? (vec ? (const void *)k_gf_ws_solve<2, true, false, true, 1> : (const void *)k_gf_ws_solve<2, false, false, true, 1>)
+                                  : (vec ? (const void *)k_gf_ws_solve<1, true, false, true, 1> : (const void *)k_gf_ws_solve<1, false, false, true, 1>);
+    // Two waves per strip (512 columns; aligned path only) cover the width with fewer lane-columns -- 1920 columns, r = 40:
+    // 5 x 512 against 11 x 256 (-9 %), 3840 columns: 9 x 512 against 22 x 256 (-18 %) -- and measure within 1 % of the
+    // one-wave form at 1080p and -4.5 % (solve only) at 4K: the two waves meet at a barrier twice per row and the kernel is
+    // latency-bound per wave, so the saved wave-rows come back as waiting.  Kept for A/B: UWIP_GF_NW=2.
+    int nw = 1;
+    if (vec && 512 - 2 * r > 0) {
+        const char *e = getenv("UWIP_GF_NW");
+        if (e && (atoi(e) == 1 || atoi(e) == 2)) nw = atoi(e);
+    }
+    const int TSs = 256 * nw - 2 * r;                       // outputs per strip of the solve kernel
+    const unsigned strips_s = uwip_cdiv(W, TSs);
     // solve: every row chunk re-reads 2r warm-up rows, so use as few chunks as keep the chip full, preferring a whole
     // number of "rounds" of resident waves.  A chunk is at least 2r+1 rows (k_gf_ws_final relies on it).
     int c = 1;
@@ -680,7 +724,7 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
             const double slots = slots_of(ksolve);
             double best_cost = 1e300;
             for (int t = 1; t <= 16 && t <= cmax; ++t) {
-                const double waves = (double)strips * zs * t;
+                const double waves = (double)strips_s * nw * zs * t;
                 const double rounds = std::max(1.0, std::ceil(waves / slots));
                 const double cost = rounds * ((double)((H + t - 1) / t) + 2.0 * r);
                 if (cost < best_cost * 0.97) { best_cost = cost; c = t; }
@@ -690,20 +734,26 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
     int rpc = (H + c - 1) / c;
     if (rpc < D) rpc = D;
     {
-        const uint3 nb = make_uint3(strips, uwip_cdiv(H, rpc), zs);
+        const uint3 nb = make_uint3(strips_s, uwip_cdiv(H, rpc), zs);
         const unsigned grid = 8u * ((nb.x * nb.y * nb.z + 7u) / 8u);
         uwip_kscope ks(ctx, "k_gf_ws_solve");
         const int fdiv = np / knp;
         const uwip_gf_pu8 none{};
+        const uwip_gf_pu8 &pa = pu8 ? *pu8 : none;
+#define UWIP_GF_SOLVE(NPV, VECV, PU8V, C3V, NWV)                                                                                     \
+    k_gf_ws_solve<NPV, VECV, PU8V, C3V, NWV><<<grid, 64 * NWV, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, \
+                                                                               TSs, rpc, fdiv, nb, pa)
+        const bool c3 = nw == 1 && TSs <= 192;
         if (pu8) {
-            { if (TS <= 192) k_gf_ws_solve<2, true, true, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, *pu8); else k_gf_ws_solve<2, true, true, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, *pu8); }
+            if (nw == 2) UWIP_GF_SOLVE(2, true, true, false, 2); else if (c3) UWIP_GF_SOLVE(2, true, true, true, 1); else UWIP_GF_SOLVE(2, true, true, false, 1);
         } else if (knp == 2) {
-            if (vec) { if (TS <= 192) k_gf_ws_solve<2, true, false, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); else k_gf_ws_solve<2, true, false, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); }
-            else { if (TS <= 192) k_gf_ws_solve<2, false, false, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); else k_gf_ws_solve<2, false, false, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); }
+            if (vec) { if (nw == 2) UWIP_GF_SOLVE(2, true, false, false, 2); else if (c3) UWIP_GF_SOLVE(2, true, false, true, 1); else UWIP_GF_SOLVE(2, true, false, false, 1); }
+            else { if (c3) UWIP_GF_SOLVE(2, false, false, true, 1); else UWIP_GF_SOLVE(2, false, false, false, 1); }
         } else {
-            if (vec) { if (TS <= 192) k_gf_ws_solve<1, true, false, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); else k_gf_ws_solve<1, true, false, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); }
-            else { if (TS <= 192) k_gf_ws_solve<1, false, false, true><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); else k_gf_ws_solve<1, false, false, false><<<grid, 64, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, TS, rpc, fdiv, nb, none); }
+            if (vec) { if (nw == 2) UWIP_GF_SOLVE(1, true, false, false, 2); else if (c3) UWIP_GF_SOLVE(1, true, false, true, 1); else UWIP_GF_SOLVE(1, true, false, false, 1); }
+            else { if (c3) UWIP_GF_SOLVE(1, false, false, true, 1); else UWIP_GF_SOLVE(1, false, false, false, 1); }
         }
+#undef UWIP_GF_SOLVE
     }
     {
         // final: chains are independent, so split the 2r+1 chain starts over enough waves for ~4 rounds
