@@ -531,7 +531,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
                                                      int items_per_block,
                                                      uint32_t *__restrict__ out_hist /*[F][51][256]*/,
                                                      size_t out_fs, const uint32_t *__restrict__ tile_max /*[F][tiles]*/,
-                                                     ClipList cl)
+                                                     ClipList cl, int rem_mode)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_sweep[];
     uint32_t *s_pack = s_sweep;                                   // [SWEEP_GROUP][256]
@@ -624,9 +624,36 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
         // ceil(rem / 64) waves run the last round instead of all eight with a few lanes each (a 61 x 34 cell of the 32 x 32
         // grid has 4 whole groups + 26 pixels: 5 rounds for every wave became 4 + one wave's).
         const int nfull = npix / SWEEP_THREADS, rem = npix - nfull * SWEEP_THREADS;
-        const int ntot = nfull + (tid < rem ? 1 : 0);
+        // A SMALL remainder is not given a round of its own at all (the block would wait a whole round for one wave): its
+        // rem x nl evaluations -- nl per pixel: the distinct limits, + the separate G evaluation -- are dealt one per thread,
+        // a thread = (pixel, evaluation).  Same counts in the same counters.
+        const int nl = (nd == SWEEP_GROUP ? SWEEP_GROUP : nd) + (g_sep ? 1 : 0);
+        const bool rem_spread = rem_mode == 2 && rem > 0 && rem * nl <= 4 * SWEEP_THREADS;
+        if (rem_spread) {
+            for (int idx = tid; idx < rem * nl; idx += SWEEP_THREADS) {
+                const int pp = idx / nl, e = idx - pp * nl;
+                int x, y;
+                locate(nfull * SWEEP_THREADS + pp, x, y);
+                const uint32_t v = pix_at(x, y);
+                const float txf = (float)x * inv_tw - 0.5f;
+                const float xa = txf - floorf(txf), xa1 = 1.0f - xa;
+                const float tyf = (float)y * inv_th - 0.5f;
+                const float ya = tyf - floorf(tyf), ya1 = 1.0f - ya;
+                const uint32_t *pack_v = s_pack + v;
+                if (g_sep && e == nl - 1) { atomicAdd(&s_g[sweep_eval(pack_v[0], xa1, xa, ya1, ya)], 65536u); continue; }
+                const uint32_t o = sweep_eval(pack_v[e * 256], xa1, xa, ya1, ya);
+                if (nd == SWEEP_GROUP || e < ns) atomicAdd(&my_hist[(e >> 1) * 256 + o], (e & 1) ? 65536u : 1u);
+                else {                                              // e == ns: the last distinct limit -> tail histogram
+                    atomicAdd(&s_tail[(ns >> 1) * 256 + o], (ns & 1) ? 65536u : 1u);
+                    if (g_last) atomicAdd(&s_g[o], 65536u);
+                }
+            }
+        }
+        // rem_mode 0 (diagnostic): the remainder by the spread mapping too, i.e. every wave runs the last round with a few lanes
+        const int rem_pos = rem_mode == 0 ? pix_of(0) : tid;
+        const int ntot = nfull + ((!rem_spread && rem_pos < rem) ? 1 : 0);
         int t = 0;
-        if (ntot > 0) { locate(nfull > 0 ? pix_of(0) : tid, xn, yn); vnext = pix_at(xn, yn); }
+        if (ntot > 0) { locate(nfull > 0 ? pix_of(0) : rem_pos, xn, yn); vnext = pix_at(xn, yn); }
         // a thread's next pixel is SWEEP_THREADS further along the cell: step (x, y) instead of dividing again
         const int dq = SWEEP_THREADS / w, dr = SWEEP_THREADS - dq * w;     // wave-uniform
         for (; t < ntot;) {
@@ -638,7 +665,7 @@ __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__
                     xn += dr; yn += dq;
                     if (xn >= ci.x1) { xn -= w; yn++; }
                 } else {
-                    locate(nfull * SWEEP_THREADS + tid, xn, yn);      // the remainder pixel
+                    locate(nfull * SWEEP_THREADS + rem_pos, xn, yn);      // the remainder pixel
                 }
                 vnext = pix_at(xn, yn);
             }
@@ -1144,11 +1171,15 @@ UWIP_API int uwip_aclahe_sweep_hist(uwip_ctx *ctx, const uwip_batch_u8 *src, int
         dim3 grid(uwip_cdiv(nitems, ipb), SWEEP_NCL / SWEEP_GROUP, (unsigned)F);
         uwip_kscope ks(ctx, "k_clahe_sweep");
         const size_t sweep_lds = sizeof(uint32_t) * SWEEP_LDS_WORDS;
+        // how a cell's npix mod 512 pixels are walked (UWIP_SWEEP_REM; same box, 64-frame sweeps, tools/sweep_ab.py): 0 = round 2's
+        // spread round, every wave with a few lanes: 7.93 ms; 1 = one contiguous round, one wave's worth: 7.67 ms (default);
+        // 2 = small remainders as (pixel, evaluation) threads: 7.78 ms
+        static const int rem_mode = [] { const char *e = getenv("UWIP_SWEEP_REM"); return e && *e >= '0' && *e <= '2' ? *e - '0' : 1; }();
         rc = uwip_lds_optin(ctx, "k_clahe_sweep", (const void *)k_clahe_sweep, sweep_lds);
         if (rc) return rc;
         k_clahe_sweep<<<grid, SWEEP_THREADS, sweep_lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.gx,
                                                      g.gy, g.inv_tw, g.inv_th, d_luts, d_items, nitems, ipb,
-                                                     d_out + (size_t)gi * SWEEP_NCL * 256, out_fs, d_tmax, cl);
+                                                     d_out + (size_t)gi * SWEEP_NCL * 256, out_fs, d_tmax, cl, rem_mode);
         UWIP_HIP(ctx, hipGetLastError());
     }
     {
