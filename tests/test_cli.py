@@ -189,6 +189,18 @@ def test_videostrip_cli_selector_and_report(tmp_path, orc):
             if eof:
                 break
     assert [(r_[0], r_[1]) for r_ in rows] == exp, (rows, exp)
+    # --gpus N: per-slice extraction on N contexts (both on this box's one GPU), decision chain with look-ahead on GPU 0:
+    # the same report, value for value
+    for g in (1, 3):
+        prefix_g = str(tmp_path / f"g{g}_")
+        r = subprocess.run([os.path.join(BIN, "videostrip"), "-k", str(k), "-p", str(p), "--png", "-g", str(g), lst, prefix_g],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        rep_g = open(prefix_g + "videostrip_report.txt").read().splitlines()
+        rows_g = [l.split("\t") for l in rep_g[rep_g.index("ID\tFrame\tFilename\tOverlap\tBlur") + 1:]]
+        assert [(a[0], a[1], a[3], a[4]) for a in rows_g] == [(a[0], a[1], a[3], a[4]) for a in rows], (g, rows_g, rows)
+        for i in range(len(rows)):
+            assert np.array_equal(_load_png(prefix_g + f"{i:04d}.png"), _load_png(prefix + f"{i:04d}.png"))
     # the Python mirror of the loop (uwimageproc_amd.videostrip.select_keyframes) agrees with the CLI
     import torch
     import uwimageproc_amd as uw
