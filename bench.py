@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--config", choices=["1080p", "4k", "4k-paced"], default="1080p",
                     help="1080p: BASELINE.json's metric (default); 4k: the same pipe on 3840x2160 frames (configs 3/5), 64 frames per "
                          "step; 4k-paced: config 5's stream mode -- 600 frames arriving at 60 fps through host buffers, then unpaced")
-    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 512 at 1080p, 64 at 4K)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 512 at 1080p, 128 at 4K)")
     ap.add_argument("--rows", type=int, default=None)
     ap.add_argument("--cols", type=int, default=None)
     ap.add_argument("--paced-fps", type=float, default=60.0)
@@ -66,7 +66,7 @@ def parse():
     big = a.config != "1080p"
     a.rows = a.rows or (2160 if big else 1080)
     a.cols = a.cols or (3840 if big else 1920)
-    a.frames = a.frames or (64 if big else 512)
+    a.frames = a.frames or (128 if big else 512)
     return a
 
 
@@ -572,10 +572,10 @@ def host_leg(rig, world, steps):
 
 
 def fourk_leg(args, dev_index, dev, rank, world):
-    """BASELINE configs 3 / 5 inside the default line: the same pipe on 3840x2160 frames (64 per GPU and step), 6 steps
+    """BASELINE configs 3 / 5 inside the default line: the same pipe on 3840x2160 frames (128 per GPU and step), 6 steps
     HBM-resident and 6 steps through host buffers, then config 5's paced 4K@60 stream (a short one: 2 s) on every rank."""
     from uwimageproc_amd import sharding
-    H, W, F, S = 2160, 3840, 64, max(1, args.streams)
+    H, W, F, S = 2160, 3840, 128, max(1, args.streams)
     rig = Rig(dev_index, dev, F, H, W, S, 1234 + 1000 * rank)        # the same scene as --config 4k
     steps = 6
     dt = timed(rig, world, steps, 1, host=False)
