@@ -39,7 +39,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=["1080p", "4k", "4k-paced"], default="1080p",
-                    help="1080p: BASELINE.json's metric (default); 4k: the same pipe on 3840x2160 frames (configs 3/5), 64 frames per "
+                    help="1080p: BASELINE.json's metric (default); 4k: the same pipe on 3840x2160 frames (configs 3/5), 128 frames per "
                          "step; 4k-paced: config 5's stream mode -- 600 frames arriving at 60 fps through host buffers, then unpaced")
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 512 at 1080p, 128 at 4K)")
     ap.add_argument("--rows", type=int, default=None)
