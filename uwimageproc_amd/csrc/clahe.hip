@@ -182,6 +182,16 @@ __global__ __launch_bounds__(256) void k_gauss3_u8(const uint8_t *__restrict__ s
 // loop over the few padded columns; padded rows are index math.
 constexpr int TH_REP = 4;
 constexpr int TH_RSTRIDE = 256 + 8;
+// BP (tiles of >= TH_BP_MIN pixels whose rows are 16-byte aligned runs: the 2x2 ... 8x8 grids of a 1080p or 4K frame): a
+// slot-keyed layout -- TH_BP_SLOTS slots per PAIR of bins, two 16-bit counters per word, lane l counts in slot l mod 16 (a
+// slot sees the pixels of four lanes: < 65536 for any part below 1 M pixels), 8 KB per wave -- read with 16 pixels per
+// lane and load, four row patches in flight.  Measured per 64 frames (tools/tilehist_only.py): replica form 56-62 us;
+// 32 slots (one lane pair per bank, 16 KB per wave, 8 waves per CU) 51 us; 16 slots 40 us; 8 slots 59 us; 4 slots 74 us;
+// 2 / 4 / 8 row patches in flight 42-45 / 40 / 40 us.  The flush adds the slots of a bin with a lane-rotated slot index.
+constexpr int TH_BP_MIN = 8192;
+constexpr int TH_BP_SLOTS = 16;
+constexpr int TH_BP_WORDS = 128 * TH_BP_SLOTS;
+template <bool BP>
 __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restrict__ src,
                                                         size_t step, size_t fstride, int rows,
                                                         int cols, int gx, int tw, int th, int split,
@@ -189,25 +199,59 @@ __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restric
                                                         const int *__restrict__ frame_map,
                                                         uint32_t *__restrict__ hists, int tiles)
 {
-    __shared__ uint32_t sh[4][TH_REP * TH_RSTRIDE];
+    constexpr int HWORDS = BP ? TH_BP_WORDS : TH_REP * TH_RSTRIDE;
+    __shared__ __attribute__((aligned(16))) uint32_t sh[4][HWORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int item = blockIdx.x * 4 + wave;
     if (item >= tiles * split) return;
     uint32_t *H = sh[wave];
-    for (int i = lane; i < TH_REP * TH_RSTRIDE; i += 64) H[i] = 0;
+    if (BP) for (int i = lane; i < HWORDS / 4; i += 64) reinterpret_cast<uint4 *>(H)[i] = make_uint4(0, 0, 0, 0);
+    else for (int i = lane; i < HWORDS; i += 64) H[i] = 0;
     const int t = item / split, part = item - t * split;
     const int ty = t / gx, tx = t - ty * gx;
     const int f = blockIdx.y;
     const int fr = frame_map ? frame_map[f] : f;
     const uint8_t *base = src + (size_t)fr * fstride;
     const int j0 = part * rows_per_part, j1 = min(th, j0 + rows_per_part);
-    uint32_t *my = H + (lane % TH_REP) * TH_RSTRIDE;
+    uint32_t *my = BP ? H + (lane & (TH_BP_SLOTS - 1)) : H + (lane % TH_REP) * TH_RSTRIDE;
+    // count one pixel of value v
+    auto add = [&](uint32_t v) {
+        if (BP) atomicAdd(&my[(v >> 1) * TH_BP_SLOTS], (v & 1u) ? 65536u : 1u);
+        else atomicAdd(&my[v], 1u);
+    };
     const int xs = tx * tw, xe = max(xs, min(xs + tw, cols));   // in-image columns [xs, xe); [xe, xs + tw) is reflected padding
     const bool vec = ((reinterpret_cast<uintptr_t>(base) | step) & 3u) == 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (xe > xs) {
+    if constexpr (BP) {
+        // fast path (host guarantees: rows 16-byte aligned, tw a multiple of 16, no padded columns): 16 pixels per lane
+        // and load, the wave covers RW rows x CW 16-byte units, four such patches in flight (4 KB per wave: at 8 waves
+        // per CU that is what the HBM latency needs)
+        const int n16 = tw >> 4, CW = min(n16, 64), RW = 64 / CW;
+        const int r = lane / CW, c = lane - r * CW;
+        if (r < RW) {
+            for (int cb = c; cb < n16; cb += 64) {
+                const uint8_t *colp = base + xs + cb * 16;
+                constexpr int U = 4;
+                for (int j = j0 + r; j < j1; j += RW * U) {
+                    uint4 w[U];
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int jj = min(j + u * RW, j1 - 1);           // clamped: a duplicate row is loaded, not counted
+                        w[u] = *reinterpret_cast<const uint4 *>(colp + (size_t)reflect101(ty * th + jj, rows) * step);
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        if (j + u * RW >= j1) break;
+                        const uint32_t q[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { add(q[k] & 255u); add((q[k] >> 8) & 255u); add((q[k] >> 16) & 255u); add(q[k] >> 24); }
+                    }
+                }
+            }
+        }
+    } else if (xe > xs) {
         // units along a row: aligned dwords (vec) or single pixels; the wave covers a patch of RW rows x CW units
         const int u0 = vec ? (xs >> 2) : xs, nu = vec ? ((xe + 3) >> 2) - u0 : xe - xs;
         const int CW = min(nu, 64), RW = 64 / CW;
@@ -226,11 +270,10 @@ __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restric
                 for (int j = j0 + r; j < j1; j += RW) {
                     const int y = reflect101(ty * th + j, rows);
                     const uint8_t *row = base + (size_t)y * step;
-                    if (!vec) { atomicAdd(&my[row[u]], 1u); continue; }
+                    if (!vec) { add(row[u]); continue; }
                     if (bmask == 0xfu) {
                         const uint32_t w = reinterpret_cast<const uint32_t *>(row)[u];
-                        atomicAdd(&my[w & 255u], 1u); atomicAdd(&my[(w >> 8) & 255u], 1u);
-                        atomicAdd(&my[(w >> 16) & 255u], 1u); atomicAdd(&my[w >> 24], 1u);
+                        add(w & 255u); add((w >> 8) & 255u); add((w >> 16) & 255u); add(w >> 24);
                     } else {
                         uint32_t w = 0;
                         if (whole) w = reinterpret_cast<const uint32_t *>(row)[u];
@@ -239,25 +282,38 @@ __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restric
                             for (int k = 0; k < 4; ++k) if (bmask & (1u << k)) w |= (uint32_t)row[4 * u + k] << (8 * k);
                         }
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) if (bmask & (1u << k)) atomicAdd(&my[(w >> (8 * k)) & 255u], 1u);
+                        for (int k = 0; k < 4; ++k) if (bmask & (1u << k)) add((w >> (8 * k)) & 255u);
                     }
                 }
             }
         }
     }
     // reflected padding columns [xe, xs + tw): a handful per row
-    const int npad = xs + tw - xe;
+    const int npad = BP ? 0 : xs + tw - xe;
     if (npad > 0) {
         for (int i = lane; i < npad * (j1 - j0); i += 64) {
             const int jr = i / npad, x = xe + (i - jr * npad);
             const int y = reflect101(ty * th + j0 + jr, rows);
-            atomicAdd(&my[base[(size_t)y * step + reflect101(x, cols)]], 1u);
+            add(base[(size_t)y * step + reflect101(x, cols)]);
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     uint32_t *out = hists + ((size_t)f * tiles + t) * 256;
+    if (BP) {
+        for (int bp = lane; bp < 128; bp += 64) {
+            uint32_t lo = 0, hi = 0;
+#pragma unroll 8
+            for (int q = 0; q < TH_BP_SLOTS; ++q) {
+                const uint32_t w = H[bp * TH_BP_SLOTS + ((q + lane) & (TH_BP_SLOTS - 1))];      // lane-rotated slot: spreads the banks
+                lo += w & 0xffffu; hi += w >> 16;
+            }
+            if (split == 1) { out[2 * bp] = lo; out[2 * bp + 1] = hi; }
+            else { if (lo) atomicAdd(&out[2 * bp], lo); if (hi) atomicAdd(&out[2 * bp + 1], hi); }
+        }
+        return;
+    }
     for (int bn = lane; bn < 256; bn += 64) {
         uint32_t sum = 0;
 #pragma unroll
@@ -764,17 +820,30 @@ int launch_tilehist(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g,
                     int nf, uint32_t *d_hists)
 {
     const int tiles = g.gx * g.gy;
-    // one wave per (tile, row part): enough parts for >= 16384 waves, at least 8 rows each
-    int split = (int)((16384 + (size_t)tiles * nf - 1) / ((size_t)tiles * nf));
-    split = std::max(1, std::min(split, std::max(1, g.th / 8)));
+    // one wave per (tile, row part).  Large aligned tiles take the slot-keyed form: parts of >= TH_BP_MIN pixels, enough of
+    // them for ~4096 waves; small or unaligned tiles the replica form: enough parts for >= 16384 waves, at
+    // least 8 rows each.
+    const bool bp = (long long)g.tw * g.th >= TH_BP_MIN && (g.tw & 15) == 0 && g.tw * g.gx == g.cols &&
+                    ((reinterpret_cast<uintptr_t>(src->data) | src->step | src->frame_stride) & 15u) == 0;
+    int split;
+    if (bp) {
+        split = (int)((4096 + (size_t)tiles * nf - 1) / ((size_t)tiles * nf));
+        split = std::max(1, std::min(split, (int)(((long long)g.tw * g.th) / TH_BP_MIN)));
+    } else {
+        split = (int)((16384 + (size_t)tiles * nf - 1) / ((size_t)tiles * nf));
+        split = std::max(1, std::min(split, std::max(1, g.th / 8)));
+    }
     const int rpp = (g.th + split - 1) / split;
     split = (g.th + rpp - 1) / rpp;                       // no empty parts
     if (split > 1) UWIP_HIP(ctx, hipMemsetAsync(d_hists, 0, sizeof(uint32_t) * 256 * (size_t)tiles * nf, ctx->stream));
     dim3 grid((unsigned)((tiles * split + 3) / 4), (unsigned)nf);
     uwip_kscope ks(ctx, "k_clahe_tilehist");
-    k_clahe_tilehist<<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
-                                                    g.rows, g.cols, g.gx, g.tw, g.th, split, rpp,
-                                                    d_frame_map, d_hists, tiles);
+    if (bp)
+        k_clahe_tilehist<true><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.rows, g.cols,
+                                                              g.gx, g.tw, g.th, split, rpp, d_frame_map, d_hists, tiles);
+    else
+        k_clahe_tilehist<false><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.rows, g.cols,
+                                                               g.gx, g.tw, g.th, split, rpp, d_frame_map, d_hists, tiles);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
