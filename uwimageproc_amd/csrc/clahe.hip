@@ -398,28 +398,15 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
     }
 }
 
-// ---- pack the four neighbour LUTs of every interpolation cell: one uint32 per grey level --------
-// packed[f][cy][cx][v] = TL | TR<<8 | BL<<16 | BR<<24 with TL = lut[max(cy-1,0)][max(cx-1,0)][v] etc.
-__global__ __launch_bounds__(256) void k_clahe_pack(const uint8_t *__restrict__ luts, size_t lut_fs, int gx, int gy,
-                                                    uint32_t *__restrict__ packed)
-{
-    const int v = threadIdx.x, cx = blockIdx.x, cy = blockIdx.y, f = blockIdx.z;
-    const uint8_t *L = luts + (size_t)f * lut_fs;
-    const int ty1 = max(cy - 1, 0), ty2 = min(cy, gy - 1), tx1 = max(cx - 1, 0), tx2 = min(cx, gx - 1);
-    const uint32_t a = L[((size_t)ty1 * gx + tx1) * 256 + v], b = L[((size_t)ty1 * gx + tx2) * 256 + v];
-    const uint32_t c = L[((size_t)ty2 * gx + tx1) * 256 + v], d = L[((size_t)ty2 * gx + tx2) * 256 + v];
-    packed[(((size_t)f * (gy + 1) + cy) * (gx + 1) + cx) * 256 + v] = a | (b << 8) | (c << 16) | (d << 24);
-}
-
 // ---- C1c: bilinear LUT interpolation, strip per block -------------------------
 // strips[s] = (cy, r0, r1, unused): rows [r0,r1) all have floor(y*inv_th-0.5)+1 == cy.
 // One launch may mix tile grids (the per-frame parameters of the aclahe stage): a per-frame descriptor then
 // replaces the launch-wide geometry, so that 64 frames stay ONE long launch instead of one short launch per grid size.
 struct ApplyFrame {
     const int4 *strips;     // this frame's strip list
-    const uint8_t *packed;  // its packed LUT rows [(gy+1)][(gx+1)][256] uint32
+    const uint8_t *luts;    // its tile LUTs [gy * gx][256]
     int fr;                 // frame index in src / dst
-    int nstrips, gx, TX, xs;    // xs: column parts per strip
+    int nstrips, gx, gy, TX, xs;    // xs: column parts per strip
     float inv_tw, inv_th;
 };
 template <bool VEC>
@@ -440,7 +427,7 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
     int nstrips = (int)gridDim.x / max(xs, 1);
     if (desc) {                                     // block-uniform
         const ApplyFrame d = desc[f];
-        strips = d.strips; lbase = d.packed; fr = d.fr; gx = d.gx; TX = d.TX; xs = d.xs; inv_tw = d.inv_tw; inv_th = d.inv_th;
+        strips = d.strips; lbase = d.luts; fr = d.fr; gx = d.gx; gy = d.gy; TX = d.TX; xs = d.xs; inv_tw = d.inv_tw; inv_th = d.inv_th;
         nstrips = d.nstrips;
     }
     // A block = one strip of rows that share (ty1, ty2) x one of xs column parts: the LUT row it stages (1 KB per
@@ -456,10 +443,25 @@ __global__ __launch_bounds__(256) void k_clahe_apply(const uint8_t *__restrict__
     // cells touched by columns [8 g_lo, 8 g_hi): cell(x) = floor(x * inv_tw - 0.5) + 1, non-decreasing in x
     const int c_lo = (int)floorf((float)(g_lo * 8) * inv_tw - 0.5f) + 1;
     const int c_hi = (int)floorf((float)(min(g_hi * 8, cols) - 1) * inv_tw - 0.5f) + 1;
-    // the packed LUT row of this strip's cell row: (gx+1)*256 uint32, pre-packed by k_clahe_pack
-    const uint4 *P4 = reinterpret_cast<const uint4 *>(lbase + ((size_t)cy * (gx + 1) + c_lo) * 1024);
-    for (int idx = tid; idx < (c_hi - c_lo + 1) * 64; idx += 256) reinterpret_cast<uint4 *>(s_pack)[idx] = P4[idx];
-    (void)gy;
+    // the packed LUT row of this strip's cells, built while it is staged: entry v of interpolation cell c holds the four
+    // neighbour tiles' LUT bytes TL | TR << 8 | BL << 16 | BR << 24.  A thread takes four grey levels of a cell: one dword
+    // from each of the four tile LUTs (L2 hits: a tile serves four cells and every strip of its cell rows), byte-
+    // transposed by v_perm, one 16-byte LDS store.  (Round 2 packed the rows in a kernel of its own and staged copies.)
+    {
+        const uint32_t *L4 = reinterpret_cast<const uint32_t *>(lbase);
+        const int ty1 = max(cy - 1, 0), ty2 = min(cy, gy - 1);
+        for (int idx = tid; idx < (c_hi - c_lo + 1) * 64; idx += 256) {
+            const int c = c_lo + (idx >> 6), v4 = idx & 63;
+            const int tx1 = max(c - 1, 0), tx2 = min(c, gx - 1);
+            const uint32_t a = L4[((size_t)ty1 * gx + tx1) * 64 + v4], b = L4[((size_t)ty1 * gx + tx2) * 64 + v4];
+            const uint32_t cc = L4[((size_t)ty2 * gx + tx1) * 64 + v4], d = L4[((size_t)ty2 * gx + tx2) * 64 + v4];
+            const uint32_t t0 = __builtin_amdgcn_perm(b, a, 0x05010400u), t1 = __builtin_amdgcn_perm(b, a, 0x07030602u);
+            const uint32_t u0 = __builtin_amdgcn_perm(d, cc, 0x05010400u), u1 = __builtin_amdgcn_perm(d, cc, 0x07030602u);
+            reinterpret_cast<uint4 *>(s_pack)[idx] =
+                make_uint4(__builtin_amdgcn_perm(u0, t0, 0x05040100u), __builtin_amdgcn_perm(u0, t0, 0x07060302u),
+                           __builtin_amdgcn_perm(u1, t1, 0x05040100u), __builtin_amdgcn_perm(u1, t1, 0x07060302u));
+        }
+    }
     __syncthreads();
     const uint8_t *sb = src + (size_t)fr * sfs;
     uint8_t *db = dst + (size_t)fr * dfs;
@@ -903,15 +905,6 @@ ApplyShape apply_shape(const ClaheGeom &g)
     return a;
 }
 
-// pack the LUTs of `nf` frames of one geometry into d_packed ([nf][(gy+1)][(gx+1)][256] uint32)
-int launch_pack(uwip_ctx *ctx, const ClaheGeom &g, const uint8_t *d_luts, size_t lut_fs, int nf, uint32_t *d_packed)
-{
-    uwip_kscope kp(ctx, "k_clahe_pack");
-    k_clahe_pack<<<dim3(g.gx + 1, g.gy + 1, nf), 256, 0, ctx->stream>>>(d_luts, lut_fs, g.gx, g.gy, d_packed);
-    UWIP_HIP(ctx, hipGetLastError());
-    return UWIP_OK;
-}
-
 int launch_apply(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, const ClaheGeom &g,
                  const uint8_t *d_luts, size_t lut_fs, const int *d_frame_map, int nf)
 {
@@ -924,13 +917,6 @@ int launch_apply(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *d
     const size_t lds = (size_t)sh.lds_cells * 256 * sizeof(uint32_t);
     const bool vec = aligned_for(src, 8) && aligned_for(dst, 8);
     dim3 grid((unsigned)(nstrips * sh.xs), (unsigned)nf);
-    const size_t pack_fs = (size_t)(g.gy + 1) * (g.gx + 1) * 1024;      // bytes per frame
-    uint32_t *d_packed = (uint32_t *)uwip_ws(ctx, "clahe.packed", pack_fs * nf);
-    if (!d_packed) return UWIP_ERR_NOMEM;
-    rc = launch_pack(ctx, g, d_luts, lut_fs, nf, d_packed);
-    if (rc) return rc;
-    d_luts = reinterpret_cast<const uint8_t *>(d_packed);
-    lut_fs = pack_fs;
     uwip_kscope ks(ctx, "k_clahe_apply");
     if (vec)
         k_clahe_apply<true><<<grid, 256, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride,
@@ -1088,26 +1074,24 @@ UWIP_API int uwip_clahe_per_frame(uwip_ctx *ctx, const uwip_batch_u8 *src, const
     if (!h_map || !d_map || !h_desc || !d_desc) return UWIP_ERR_NOMEM;
     UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     int *h_clip = h_map + F, *d_clip = d_map + F;
-    size_t packed_bytes = 0;
     for (int i = 0; i < F; ++i) {
         const int f = order[i];
         h_map[i] = f;
         const ClaheGeom g = make_geom(src->rows, src->cols, h_grid[f], h_grid[f]);
         h_clip[i] = clip_from_limit(h_clipLimit[f], g.area);
-        packed_bytes += (size_t)(g.gy + 1) * (g.gx + 1) * 1024;
     }
     UWIP_HIP(ctx, hipMemcpyAsync(d_map, h_map, sizeof(int) * 2 * (size_t)F, hipMemcpyHostToDevice, ctx->stream));
     size_t max_tiles = 0;
     for (int f = 0; f < F; ++f) max_tiles = std::max(max_tiles, (size_t)h_grid[f] * h_grid[f]);
     uint32_t *d_hists = (uint32_t *)uwip_ws(ctx, "clahe.tilehist", sizeof(uint32_t) * 256 * max_tiles * F);
     uint8_t *d_luts = (uint8_t *)uwip_ws(ctx, "clahe.luts", (size_t)256 * max_tiles * F);
-    uint8_t *d_packed = (uint8_t *)uwip_ws(ctx, "clahe.packed", packed_bytes);
-    if (!d_hists || !d_luts || !d_packed) return UWIP_ERR_NOMEM;
-    // per group of equal grid size: tile histograms, LUTs, packed LUT rows (small launches); the interpolation itself
+    if (!d_hists || !d_luts) return UWIP_ERR_NOMEM;
+    // per group of equal grid size: tile histograms and LUTs (small launches; every group keeps its own LUT range, the
+    // interpolation reads them all); the interpolation itself
     // then runs ONCE over all frames with a per-frame descriptor (a launch per group would be too short to reach the
     // HBM rate: at 4K 16 frames split three ways ran at 29 % of peak, the single launch at 41 %)
     int i = 0, max_blocks = 0, max_cells = 0;
-    size_t poff = 0;
+    size_t loff = 0;
     while (i < F) {
         int j = i;
         const int gsz = h_grid[order[i]];
@@ -1119,12 +1103,9 @@ UWIP_API int uwip_clahe_per_frame(uwip_ctx *ctx, const uwip_batch_u8 *src, const
         if (rc) return rc;
         ClipList cl{};
         cl.n = 1;
-        rc = launch_lut(ctx, g, d_hists, cl, d_clip + i, nf, residual_rule, d_luts);
+        rc = launch_lut(ctx, g, d_hists, cl, d_clip + i, nf, residual_rule, d_luts + loff);
         if (rc) return rc;
-        // d_hists / d_luts are reused by the next group: stream order keeps that safe
-        const size_t pack_fs = (size_t)(g.gy + 1) * (g.gx + 1) * 1024;
-        rc = launch_pack(ctx, g, d_luts, (size_t)tiles * 256, nf, (uint32_t *)(d_packed + poff));
-        if (rc) return rc;
+        // d_hists is reused by the next group: stream order keeps that safe
         const ApplyShape sh = apply_shape(g);
         const int4 *d_strips = nullptr;
         int nstrips = 0;
@@ -1132,12 +1113,12 @@ UWIP_API int uwip_clahe_per_frame(uwip_ctx *ctx, const uwip_batch_u8 *src, const
         if (rc) return rc;
         for (int k = 0; k < nf; ++k) {
             ApplyFrame &a = h_desc[i + k];
-            a.strips = d_strips; a.packed = d_packed + poff + (size_t)k * pack_fs; a.fr = order[i + k];
-            a.nstrips = nstrips; a.gx = g.gx; a.TX = sh.TX; a.xs = sh.xs; a.inv_tw = g.inv_tw; a.inv_th = g.inv_th;
+            a.strips = d_strips; a.luts = d_luts + loff + (size_t)k * tiles * 256; a.fr = order[i + k];
+            a.nstrips = nstrips; a.gx = g.gx; a.gy = g.gy; a.TX = sh.TX; a.xs = sh.xs; a.inv_tw = g.inv_tw; a.inv_th = g.inv_th;
         }
         max_blocks = std::max(max_blocks, nstrips * sh.xs);
         max_cells = std::max(max_cells, sh.lds_cells);
-        poff += pack_fs * nf;
+        loff += (size_t)tiles * 256 * nf;
         i = j;
     }
     UWIP_HIP(ctx, hipMemcpyAsync(d_desc, h_desc, sizeof(ApplyFrame) * (size_t)F, hipMemcpyHostToDevice, ctx->stream));
