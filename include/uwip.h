@@ -332,6 +332,12 @@ int uwip_overlap_detect(uwip_ctx *ctx, const uwip_batch_u8 *frames, uwip_feature
  * holds under any in-plane rotation of the camera.  UWIP_OVERLAP_UPRIGHT skips the orientation estimate (SURF's
  * `upright` parameter): rotation tolerance then ends near 20 degrees. */
 #define UWIP_OVERLAP_UPRIGHT 1u
+/* By default the detector threshold is relative to the frame's own contrast: 1e-3 * min(1, (k / 0.5)^2), k = the frame's
+ * contrast factor (70th percentile of the gradient magnitude).  The determinant-of-Hessian response scales with the
+ * square of the contrast, and raw frames of turbid water -- what the reference's videostrip is run on -- have none above a
+ * fixed threshold (the reference's own photograph PIS_T1A_259: no keypoint at all at 1e-3, 130 with the relative one).
+ * UWIP_OVERLAP_FIXED_THRESHOLD keeps 1e-3 (SURF's hessianThreshold, videostrip.cpp:206, is fixed as well). */
+#define UWIP_OVERLAP_FIXED_THRESHOLD 2u
 int uwip_overlap_detect_ex(uwip_ctx *ctx, const uwip_batch_u8 *frames, uwip_features *feats, int first_slot, unsigned flags);
 /* parity taps: one slot's keypoints (uwip_keypoint[2048]) / packed 64-byte descriptors; and the
  * scale-space images of frame `frame` of the most recent uwip_overlap_detect call (host buffers

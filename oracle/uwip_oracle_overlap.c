@@ -35,6 +35,7 @@
 #define OV_DESC_BYTES 64
 #define OV_BORDER 8
 #define OV_DTHRESH 0.001f
+#define OV_KC_REF 0.5f      /* contrast factor at and above which the detector threshold is OV_DTHRESH itself */
 #define OV_RANSAC_ITERS 512
 
 typedef struct {
@@ -312,9 +313,20 @@ static void build_scale_space(const uint8_t *gray, int h, int w, scale_space *S)
 }
 
 /* ---------------- detector --------------------------------------------------- */
-static int detect(const scale_space *S, orc_keypoint *kps /* OV_MAXKP */)
+/* The determinant-of-Hessian response scales with the SQUARE of the image contrast, and raw frames of turbid water have
+ * little of it (the reference's photograph PIS_T1A_259: grey levels 81..146, strongest response 4.7e-5 -- no keypoint at
+ * all above a fixed 1e-3, so calcOverlap answers -2.0 for every frame and the selector never moves on).  The threshold
+ * is therefore taken relative to the frame's own contrast factor k (the 70th percentile of the gradient magnitude, already
+ * computed for the diffusion): OV_DTHRESH * min(1, (k / OV_KC_REF)^2).  A frame as contrasted as the reference's
+ * BUL_T1A_0028 (k = 0.51) keeps 1e-3; PIS_T1A_259 (k = 0.041) gets 6.7e-6 and 130 keypoints, and its overlap under yaw and
+ * zoom is found within 0.004 (tests).  flags bit 1 keeps the fixed threshold (SURF's hessianThreshold is fixed too). */
+static int detect(const scale_space *S, orc_keypoint *kps /* OV_MAXKP */, int flags)
 {
     const int h = S->h, w = S->w;
+    const float kr = S->kcontrast / OV_KC_REF;
+    float ks = kr * kr;
+    if (!(ks < 1.0f)) ks = 1.0f;
+    const float dthr = (flags & 2) ? OV_DTHRESH : OV_DTHRESH * ks;
     size_t cap = 65536, cnt = 0;
     orc_keypoint *all = (orc_keypoint *)malloc(cap * sizeof(orc_keypoint));
     for (int lv = 0; lv < OV_NLEVELS; ++lv) {
@@ -322,7 +334,7 @@ static int detect(const scale_space *S, orc_keypoint *kps /* OV_MAXKP */)
         for (int y = OV_BORDER; y < h - OV_BORDER; ++y)
             for (int x = OV_BORDER; x < w - OV_BORDER; ++x) {
                 const float v = D[(size_t)y * w + x];
-                if (!(v > OV_DTHRESH)) continue;
+                if (!(v > dthr)) continue;
                 int ok = 1;
                 for (int dy = -1; dy <= 1 && ok; ++dy)
                     for (int dx = -1; dx <= 1; ++dx) {
@@ -542,12 +554,12 @@ static void describe(const scale_space *S, const orc_keypoint *kps, int n, uint8
     }
 }
 
-/* flags: bit 0 = upright (no orientation estimate: SURF's `upright` parameter) */
+/* flags: bit 0 = upright (no orientation estimate: SURF's `upright` parameter); bit 1 = fixed detector threshold */
 ORC_API int orc_detect_describe_ex(const uint8_t *gray, int h, int w, orc_keypoint *kps, uint8_t *desc, float *kcontrast, int flags)
 {
     scale_space S;
     build_scale_space(gray, h, w, &S);
-    int n = detect(&S, kps);
+    int n = detect(&S, kps, flags);
     for (int q = 0; q < n; ++q) {
         if (flags & 1) { kps[q].co = 1.0f; kps[q].si = 0.0f; }
         else orient(&S, &kps[q]);
@@ -950,7 +962,7 @@ ORC_API float orc_calcOverlap(const uint8_t *key, const uint8_t *obj, int rows, 
     return orc_calcOverlap_ex(key, obj, rows, cols, step, videoWidth, videoHeight, seed, info, Hout, 0);
 }
 
-/* flags: bit 0 = upright descriptors */
+/* flags: bit 0 = upright descriptors, bit 1 = fixed detector threshold */
 ORC_API float orc_calcOverlap_ex(const uint8_t *key, const uint8_t *obj, int rows, int cols, size_t step, int videoWidth,
                                  int videoHeight, uint32_t seed, int32_t *info, double *Hout, int flags)
 {

@@ -145,12 +145,12 @@ class Oracle:
         self.lib.orc_resize_gray(img, img.shape[0], img.shape[1], img.strides[0], oh, ow, g, small.ctypes.data)
         return small
 
-    def detect_describe(self, gray, upright=False):
+    def detect_describe(self, gray, upright=False, fixed_threshold=False):
         gray = np.ascontiguousarray(gray)
         kps = np.zeros(2048, self.KP)
         desc = np.zeros((2048, 64), np.uint8)
         kc = C.c_float(0)
-        n = self.lib.orc_detect_describe_ex(gray, gray.shape[0], gray.shape[1], kps.ctypes.data, desc, C.byref(kc), 1 if upright else 0)
+        n = self.lib.orc_detect_describe_ex(gray, gray.shape[0], gray.shape[1], kps.ctypes.data, desc, C.byref(kc), (1 if upright else 0) | (2 if fixed_threshold else 0))
         return kps[:n].copy(), desc[:n].copy(), kc.value
 
     def scale_space_level(self, gray, level):
@@ -184,13 +184,13 @@ class Oracle:
         r = self.lib.orc_overlapArea(Hc, vw, vh, C.byref(cnt))
         return float(r), cnt.value
 
-    def calcOverlap(self, key, obj, vw=None, vh=None, seed=1, upright=False):
+    def calcOverlap(self, key, obj, vw=None, vh=None, seed=1, upright=False, fixed_threshold=False):
         key, obj = np.ascontiguousarray(key), np.ascontiguousarray(obj)
         vw = key.shape[1] if vw is None else vw
         vh = key.shape[0] if vh is None else vh
         info = (C.c_int32 * 8)()
         H = (C.c_double * 9)()
-        r = self.lib.orc_calcOverlap_ex(key, obj, key.shape[0], key.shape[1], key.strides[0], vw, vh, seed, info, H, 1 if upright else 0)
+        r = self.lib.orc_calcOverlap_ex(key, obj, key.shape[0], key.shape[1], key.strides[0], vw, vh, seed, info, H, (1 if upright else 0) | (2 if fixed_threshold else 0))
         return float(r), list(info)[:5], np.array(list(H)).reshape(3, 3)
 
     # ---- numpy-friendly wrappers ----

@@ -445,3 +445,35 @@ def test_motion_pair_homography_is_the_pixel_mapping():
     k = key[..., 0].astype(np.float64)
     interp = (k[y0, x0] * (1 - fx) + k[y0, x0 + 1] * fx) * (1 - fy) + (k[y0 + 1, x0] * (1 - fx) + k[y0 + 1, x0 + 1] * fx) * fy
     assert np.abs(interp - cur[60:180, 80:240, 0]).mean() < 1.5
+
+
+def _real_photo_pair(name, theta, scale, rows=720, cols=1280):
+    """A key view (central crop) and a yawed / zoomed / shifted view of one of the reference's photographs, resampled
+    bilinearly with fresh +-2 sensor noise, and the exact homography current -> key."""
+    import os
+    from PIL import Image
+    img = np.ascontiguousarray(np.asarray(Image.open(os.path.join(os.path.dirname(__file__), "golden", "real", name)).convert("RGB"))[..., ::-1])
+    H0, W0 = img.shape[:2]
+    oy, ox = (H0 - rows) // 2, (W0 - cols) // 2
+    yy, xx = np.meshgrid(np.arange(rows, dtype=np.float64), np.arange(cols, dtype=np.float64), indexing="ij")
+    A = synth._affine(theta, scale, 0.03 * cols, 0.01 * cols, (cols - 1) / 2.0, (rows - 1) / 2.0)
+    X = A[0, 0] * xx + A[0, 1] * yy + A[0, 2] + ox
+    Y = A[1, 0] * xx + A[1, 1] * yy + A[1, 2] + oy
+    cur = np.stack([synth._sample_bilinear(img[..., c].astype(np.float32), X, Y) for c in range(3)], axis=-1)
+    cur = np.clip(np.rint(cur + np.random.default_rng(1).integers(-2, 3, cur.shape)), 0, 255).astype(np.uint8)
+    return img[oy:oy + rows, ox:ox + cols].copy(), cur, A
+
+
+@pytest.mark.parametrize("name,theta,scale", [("in_PIS_T1A_259.jpg", 12, 1.05), ("in_PIS_T1A_259.jpg", 170, 1.0),
+                                              ("in_BUL_T1A_0028.jpg", 40, 0.9)])
+def test_overlap_on_the_references_photographs(orc, name, theta, scale):
+    """Real underwater texture instead of the synthetic scene.  PIS_T1A_259 is a RAW frame of turbid water (grey levels
+    81..146): with the fixed threshold the detector finds nothing and calcOverlap answers -2.0 whatever the motion; with the
+    contrast-relative threshold (the default) the overlap is found within the stated 0.01."""
+    key, cur, A = _real_photo_pair(name, theta, scale)
+    truth, _ = orc.overlapArea(synth.to_working_homography(A, key.shape[1]), 640, 480)
+    r, info, _ = orc.calcOverlap(key, cur, 640, 480, seed=1)
+    assert abs(r - truth) <= 0.01 and info[3] >= 30, (r, truth, info)
+    if name.startswith("in_PIS"):
+        rf, inf2, _ = orc.calcOverlap(key, cur, 640, 480, seed=1, fixed_threshold=True)
+        assert rf == -2.0 and inf2[0] == 0

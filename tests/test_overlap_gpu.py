@@ -161,6 +161,30 @@ def test_bench_stream_consecutive_frames_vs_truth(ctx, orc):
         assert abs(r - er) <= 1e-6 and abs(r - truth) <= 0.01, (j, r, truth)
 
 
+def test_hazy_real_photograph_contrast_relative_threshold(ctx, orc):
+    """The reference's raw turbid-water photograph PIS_T1A_259: device == oracle with the contrast-relative detector
+    threshold (keypoints, descriptors, ratio within 0.01 of the truth under yaw + zoom) and with the fixed one (no keypoint,
+    -2.0)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_oracle_integer import _real_photo_pair
+    vs.videoWidth, vs.videoHeight = 640, 480
+    key, cur, A = _real_photo_pair("in_PIS_T1A_259.jpg", 12, 1.05)
+    truth, _ = orc.overlapArea(synth.to_working_homography(A, key.shape[1]), 640, 480)
+    f = vs.Features(ctx, 2)
+    f.detect(_dev(np.stack([key, cur])))
+    for s_, im in enumerate((key, cur)):
+        kps, desc = f.download(s_)
+        ek, ed, _ = orc.detect_describe(orc.resize_gray(im))
+        assert len(kps) == len(ek) >= 60 and np.array_equal(kps["x"], ek["x"]) and np.array_equal(desc, ed)
+    r = float(vs.match_pairs(ctx, f, f, [1], [0], 640, 480, seed=1)["ratio"].cpu()[0])
+    er, _, _ = orc.calcOverlap(key, cur, 640, 480, seed=1)
+    assert abs(r - er) <= 1e-6 and abs(r - truth) <= 0.01
+    f.detect(_dev(np.stack([key, cur])), fixed_threshold=True)
+    assert len(f.download(0)[0]) == 0
+    assert float(vs.match_pairs(ctx, f, f, [1], [0], 640, 480, seed=1)["ratio"].cpu()[0]) == -2.0
+
+
 def test_upright_descriptor_envelope(ctx, orc):
     """What the orientation buys: with UWIP_OVERLAP_UPRIGHT (round 2's descriptor) the device still equals the oracle bit
     for bit, and both lose the overlap beyond ~20 degrees of yaw."""

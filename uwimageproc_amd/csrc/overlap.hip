@@ -28,6 +28,7 @@ constexpr int DESC_BYTES = 64;     // packed bits
 constexpr int DESC_K = 512;        // unpacked 0/1 bytes for the i8 MFMA
 constexpr int BORDER = 8;
 constexpr float DTHRESH = 0.001f;
+constexpr float KC_REF = 0.5f;       // contrast factor at and above which the detector threshold is DTHRESH itself
 constexpr int RANSAC_ITERS = 512;
 constexpr int TW = 640, TH = 480;  // TARGET_WIDTH / TARGET_HEIGHT (videostrip.hpp:48-49)
 
@@ -433,7 +434,11 @@ __global__ __launch_bounds__(256) void k_ov_ldet(const float *__restrict__ Lx, c
 
 // ---- extrema: candidate response map over all levels ------------------------------------------------
 // Ldet: [NLEV][F][h][w] (each level a dense batch); cand: [F][NLEV][h][w], response or 0
-__global__ __launch_bounds__(256) void k_ov_extrema(const float *__restrict__ Ldet, float *__restrict__ cand, int h, int w, int F)
+// The detector threshold is relative to the frame's contrast factor k (det of the Hessian scales with contrast squared;
+// raw frames of turbid water have no response above a fixed 1e-3): DTHRESH * min(1, (k / KC_REF)^2), in the oracle's
+// operations; `fixed` keeps DTHRESH (UWIP_OVERLAP_FIXED_THRESHOLD).
+__global__ __launch_bounds__(256) void k_ov_extrema(const float *__restrict__ Ldet, float *__restrict__ cand, int h, int w, int F,
+                                                   const float *__restrict__ kc, int fixed)
 {
     const int f = blockIdx.z / NLEV, lv = blockIdx.z % NLEV;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -443,7 +448,11 @@ __global__ __launch_bounds__(256) void k_ov_extrema(const float *__restrict__ Ld
     float out = 0.0f;
     if (x >= BORDER && x < w - BORDER && y >= BORDER && y < h - BORDER) {
         const float v = D[(size_t)y * w + x];
-        bool ok = v > DTHRESH;
+        const float kr = kc[f] / KC_REF;
+        float ks = kr * kr;
+        if (!(ks < 1.0f)) ks = 1.0f;
+        const float dthr = fixed ? DTHRESH : DTHRESH * ks;
+        bool ok = v > dthr;
         if (ok) {
 #pragma unroll
             for (int dy = -1; dy <= 1; ++dy)
@@ -1546,7 +1555,7 @@ int alloc_work(uwip_ctx *ctx, int F, int h, int w, OvWork *W)
 // Level images are stored level-major, [NLEV][F][h][w]: every level is itself a dense batch, so the per-level
 // kernels write their results in place (no staging copies).
 // detect + describe every frame whose gray/L0 already sit in W (working size h x w)
-int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features *ft, int first_slot, int upright)
+int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features *ft, int first_slot, int upright, int fixed_thr)
 {
     const size_t n = (size_t)h * w, lvl = n * F;
     const dim3 g = grid2d(w, h, F);
@@ -1607,7 +1616,7 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
     int32_t *nkp = ft->d_n + first_slot;
     {
         uwip_kscope ks(ctx, "k_ov_detect");
-        k_ov_extrema<<<grid2d(w, h, F * NLEV), 256, 0, ctx->stream>>>(W.Ldet, W.cand, h, w, F);
+        k_ov_extrema<<<grid2d(w, h, F * NLEV), 256, 0, ctx->stream>>>(W.Ldet, W.cand, h, w, F, W.kc, fixed_thr);
         UWIP_HIP(ctx, hipMemsetAsync(W.selhist, 0, sizeof(uint32_t) * 65536 * F, ctx->stream));
         k_ov_sel_hist<0><<<dim3(64, F), 256, 0, ctx->stream>>>(W.cand, n4, W.selhist, W.sel);
         k_ov_sel_pick<0><<<F, 256, 0, ctx->stream>>>(W.selhist, W.sel);
@@ -1689,7 +1698,7 @@ UWIP_API int uwip_overlap_detect_ex(uwip_ctx *ctx, const uwip_batch_u8 *frames, 
 {
     int rc = uwip_check_batch(ctx, frames, 0);
     if (rc) return rc;
-    UWIP_REQUIRE(ctx, (flags & ~(unsigned)UWIP_OVERLAP_UPRIGHT) == 0, "unknown flag");
+    UWIP_REQUIRE(ctx, (flags & ~(unsigned)(UWIP_OVERLAP_UPRIGHT | UWIP_OVERLAP_FIXED_THRESHOLD)) == 0, "unknown flag");
     UWIP_REQUIRE(ctx, feats != nullptr && feats->ctx == ctx, "feature set belongs to another context");
     UWIP_REQUIRE(ctx, first_slot >= 0 && first_slot + frames->frames <= feats->capacity, "feature set too small");
     if (frames->frames == 0) return UWIP_OK;
@@ -1723,7 +1732,8 @@ UWIP_API int uwip_overlap_detect_ex(uwip_ctx *ctx, const uwip_batch_u8 *frames, 
     }
     feats->w = w; feats->h = h;
     feats->frames = std::max(feats->frames, first_slot + F);
-    return detect_describe(ctx, W, F, h, w, feats, first_slot, (flags & UWIP_OVERLAP_UPRIGHT) ? 1 : 0);
+    return detect_describe(ctx, W, F, h, w, feats, first_slot, (flags & UWIP_OVERLAP_UPRIGHT) ? 1 : 0,
+                           (flags & UWIP_OVERLAP_FIXED_THRESHOLD) ? 1 : 0);
 }
 
 // tap for tests: one slot's keypoints / packed descriptors to the host

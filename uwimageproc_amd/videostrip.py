@@ -44,11 +44,12 @@ class Features:
         except Exception:
             pass
 
-    def detect(self, frames: torch.Tensor, first_slot: int = 0, upright: bool = False):
-        """upright: SURF's `upright` parameter (no orientation estimate); the reference runs SURF oriented"""
+    def detect(self, frames: torch.Tensor, first_slot: int = 0, upright: bool = False, fixed_threshold: bool = False):
+        """upright: SURF's `upright` parameter (no orientation estimate); the reference runs SURF oriented.
+        fixed_threshold: detector threshold 1e-3 instead of the contrast-relative one."""
         b = batch_of(frames)
         torch.cuda.current_stream(frames.device).synchronize()
-        self.ctx.call("uwip_overlap_detect_ex", C.byref(b), self._h, int(first_slot), 1 if upright else 0)
+        self.ctx.call("uwip_overlap_detect_ex", C.byref(b), self._h, int(first_slot), (1 if upright else 0) | (2 if fixed_threshold else 0))
 
     def download(self, slot: int):
         kps = np.zeros(2048, KP_DTYPE)
