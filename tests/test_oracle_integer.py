@@ -477,3 +477,14 @@ def test_overlap_on_the_references_photographs(orc, name, theta, scale):
     if name.startswith("in_PIS"):
         rf, inf2, _ = orc.calcOverlap(key, cur, 640, 480, seed=1, fixed_threshold=True)
         assert rf == -2.0 and inf2[0] == 0
+
+
+def test_overlap_noise_frames_do_not_match(orc):
+    """The contrast-relative threshold finds a few dozen "keypoints" in pure sensor noise (there is nothing else to find);
+    two independent noise frames must still come out as "not enough good matches" (-2.0), like under the fixed threshold."""
+    rng = np.random.default_rng(0)
+    for mean, sd in ((20, 2), (128, 12)):
+        a = np.clip(np.rint(rng.normal(mean, sd, (480, 854, 3))), 0, 255).astype(np.uint8)
+        b = np.clip(np.rint(rng.normal(mean, sd, (480, 854, 3))), 0, 255).astype(np.uint8)
+        assert orc.calcOverlap(a, b, 640, 480, seed=1)[0] == -2.0
+        assert orc.calcOverlap(a, b, 640, 480, seed=1, fixed_threshold=True)[0] == -2.0
