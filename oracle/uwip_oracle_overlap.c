@@ -37,6 +37,11 @@
 #define OV_DTHRESH 0.001f
 #define OV_KC_REF 0.5f      /* contrast factor at and above which the detector threshold is OV_DTHRESH itself */
 #define OV_RANSAC_ITERS 512
+/* A homography needs this many inliers to count.  The reference accepts whatever findHomography(RANSAC) returns for >= 4
+ * matches (videostrip.cpp:252-272) -- but four matches always fit SOME homography exactly, and with the contrast-relative
+ * detector threshold pure sensor noise yields a few dozen keypoints of which 4 can pass the ratio test by chance: such a
+ * fit is reported as -2.0 ("no homography"), the sentinel main.cpp:321-326 turns into "do not trigger". */
+#define OV_MIN_INLIERS 6
 
 typedef struct {
     float x, y;          /* refined position (pixels of the 640-wide image) */
@@ -764,7 +769,7 @@ ORC_API int orc_find_homography(const float *ox, const float *oy, const float *s
         for (int i = 0; i < n; ++i) cnt += is_inlier(Hc, ox[i], oy[i], sx[i], sy[i]);
         if (cnt > best) { best = cnt; best_it = it; memcpy(Hb, Hc, sizeof Hb); }
     }
-    if (best < 4 || best_it < 0) return 0;
+    if (best < OV_MIN_INLIERS || best_it < 0) return 0;
     uint8_t *inl = (uint8_t *)malloc((size_t)n);
     for (int i = 0; i < n; ++i) inl[i] = (uint8_t)is_inlier(Hb, ox[i], oy[i], sx[i], sy[i]);
     double Hr[9];

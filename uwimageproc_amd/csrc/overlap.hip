@@ -28,6 +28,7 @@ constexpr int DESC_BYTES = 64;     // packed bits
 constexpr int DESC_K = 512;        // unpacked 0/1 bytes for the i8 MFMA
 constexpr int BORDER = 8;
 constexpr float DTHRESH = 0.001f;
+constexpr int MIN_INLIERS = 6;       // a homography supported by fewer inliers is none (-2.0): four chance matches always fit one
 constexpr float KC_REF = 0.5f;       // contrast factor at and above which the detector threshold is DTHRESH itself
 constexpr int RANSAC_ITERS = 512;
 constexpr int TW = 640, TH = 480;  // TARGET_WIDTH / TARGET_HEIGHT (videostrip.hpp:48-49)
@@ -1298,7 +1299,7 @@ __global__ __launch_bounds__(256) void k_ov_geometry(const Keypoint *__restrict_
         __syncthreads();
     }
     const int best = s_best_cnt[0], best_it = s_best_it[0];
-    if (best < 4) {                                   // H.empty() -> -2.0 (videostrip.cpp:272)
+    if (best < MIN_INLIERS) {                         // H.empty() -> -2.0 (videostrip.cpp:272)
         if (tid == 0) ratio[p] = -2.0f;
         return;
     }
