@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void k_ov_ldet(const float *__restrict__ Lx, c
 // raw frames of turbid water have no response above a fixed 1e-3): DTHRESH * min(1, (k / KC_REF)^2), in the oracle's
 // operations; `fixed` keeps DTHRESH (UWIP_OVERLAP_FIXED_THRESHOLD).
 __global__ __launch_bounds__(256) void k_ov_extrema(const float *__restrict__ Ldet, float *__restrict__ cand, int h, int w, int F,
-                                                   const float *__restrict__ kc, int fixed)
+                                                   const float *__restrict__ kc, int fixed, uint32_t *__restrict__ selhist)
 {
     const int f = blockIdx.z / NLEV, lv = blockIdx.z % NLEV;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -484,7 +484,12 @@ __global__ __launch_bounds__(256) void k_ov_extrema(const float *__restrict__ Ld
                 const float ox = -(Dyy * Dx - Dxy * Dy) / det, oy = -(Dxx * Dy - Dxy * Dx) / det;
                 if (!(fabsf(ox) <= 1.0f && fabsf(oy) <= 1.0f)) ok = false;
             }
-            if (ok) out = v;
+            if (ok) {
+                out = v;
+                // first pass of the top-K radix select (k_ov_sel_hist<0>'s histogram of the high 16 response bits) counted here:
+                // candidates are a few thousand per frame, and the dense map is read once less
+                atomicAdd(&selhist[(size_t)f * 65536 + (__float_as_uint(v) >> 16)], 1u);
+            }
         }
     }
     cand[((size_t)f * NLEV + lv) * n + (size_t)y * w + x] = out;
@@ -1617,9 +1622,8 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
     int32_t *nkp = ft->d_n + first_slot;
     {
         uwip_kscope ks(ctx, "k_ov_detect");
-        k_ov_extrema<<<grid2d(w, h, F * NLEV), 256, 0, ctx->stream>>>(W.Ldet, W.cand, h, w, F, W.kc, fixed_thr);
         UWIP_HIP(ctx, hipMemsetAsync(W.selhist, 0, sizeof(uint32_t) * 65536 * F, ctx->stream));
-        k_ov_sel_hist<0><<<dim3(64, F), 256, 0, ctx->stream>>>(W.cand, n4, W.selhist, W.sel);
+        k_ov_extrema<<<grid2d(w, h, F * NLEV), 256, 0, ctx->stream>>>(W.Ldet, W.cand, h, w, F, W.kc, fixed_thr, W.selhist);
         k_ov_sel_pick<0><<<F, 256, 0, ctx->stream>>>(W.selhist, W.sel);
         UWIP_HIP(ctx, hipMemsetAsync(W.selhist, 0, sizeof(uint32_t) * 65536 * F, ctx->stream));
         k_ov_sel_hist<1><<<dim3(64, F), 256, 0, ctx->stream>>>(W.cand, n4, W.selhist, W.sel);
