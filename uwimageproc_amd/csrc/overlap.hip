@@ -722,7 +722,7 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
                                                    uint8_t *__restrict__ desc, int8_t *__restrict__ bits, int32_t *__restrict__ pop, int F,
                                                    int upright)
 {
-    __shared__ float s_v[2][112];
+    __shared__ __attribute__((aligned(16))) float2 s_v[112];     // (vx, vy) of the 109 disc samples; 109..111 stay zero
     __shared__ float s_val[29][3];
     __shared__ uint32_t s_words[16];
     __shared__ float s_patch[3][21][22];   // [plane][x offset][y offset], padded
@@ -757,17 +757,20 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
             const int y1 = min(max((int)floorf(kp.y + (float)j * sc + 0.5f), 0), h - 1);
             const float g = D_GAUSS25[abs(i)][abs(j)];
             const size_t o = (size_t)y1 * w + x1;
-            s_v[0][t] = g * X[o];
-            s_v[1][t] = g * Y[o];
+            s_v[t] = make_float2(g * X[o], g * Y[o]);
         }
+        if (lane < 3) s_v[109 + lane] = make_float2(0.0f, 0.0f);      // a zero vector is in no sector (c2 < 0 fails)
         __syncthreads();
         float sx = 0.0f, sy = 0.0f;
         if (lane < 42) {
             const float d0 = D_SECTOR[lane][0], d1 = D_SECTOR[lane][1], d2 = D_SECTOR[lane][2], d3 = D_SECTOR[lane][3];
-            for (int q2 = 0; q2 < 109; ++q2) {
-                const float vx = s_v[0][q2], vy = s_v[1][q2];
-                const float c1 = d0 * vy - d1 * vx, c2 = d2 * vy - d3 * vx;
-                if (c1 >= 0.0f && c2 < 0.0f) { sx = sx + vx; sy = sy + vy; }
+            // two samples per 16-byte LDS read (all lanes read the same address: a broadcast), same order of additions
+            for (int q2 = 0; q2 < 110; q2 += 2) {
+                const float4 p = *reinterpret_cast<const float4 *>(&s_v[q2]);
+                const float ca1 = d0 * p.y - d1 * p.x, ca2 = d2 * p.y - d3 * p.x;
+                if (ca1 >= 0.0f && ca2 < 0.0f) { sx = sx + p.x; sy = sy + p.y; }
+                const float cb1 = d0 * p.w - d1 * p.z, cb2 = d2 * p.w - d3 * p.z;
+                if (cb1 >= 0.0f && cb2 < 0.0f) { sx = sx + p.z; sy = sy + p.w; }
             }
         }
         const float m0 = sx * sx + sy * sy;
