@@ -997,20 +997,44 @@ __device__ __forceinline__ uint32_t hash32(uint32_t a)
     return a;
 }
 
-__device__ bool solve8(double A[8][9])
+// 8 x 8 Gaussian elimination with partial pivoting, the oracle's operations in the oracle's order -- but with every index
+// a compile-time constant: the pivot row is swapped in by selects against each candidate row instead of A[p][k], so the
+// 72 doubles live in registers.  (Indexed by the run-time pivot the array sat in scratch memory, and two of these solves
+// per thread were half of k_ov_geometry's 0.4 ms.)  Columns left of the pivot column are never read again, so the swap
+// and the elimination skip them.
+__device__ __forceinline__ bool solve8(double (&A)[8][9])
 {
+#pragma unroll
     for (int c = 0; c < 8; ++c) {
         int p = c;
-        for (int r = c + 1; r < 8; ++r) if (fabs(A[r][c]) > fabs(A[p][c])) p = r;
-        if (!(fabs(A[p][c]) > 1e-12)) return false;
-        if (p != c) for (int k = 0; k < 9; ++k) { const double t = A[c][k]; A[c][k] = A[p][k]; A[p][k] = t; }
+        double best = fabs(A[c][c]);
+#pragma unroll
+        for (int r = c + 1; r < 8; ++r) {
+            const double v = fabs(A[r][c]);
+            if (v > best) { best = v; p = r; }          // strict: the first of equal maxima, as `p` walks in the oracle
+        }
+        if (!(best > 1e-12)) return false;
+#pragma unroll
+        for (int r = c + 1; r < 8; ++r) {
+            const bool sw = p == r;
+#pragma unroll
+            for (int k = c; k < 9; ++k) {
+                const double a = A[c][k], b = A[r][k];
+                A[c][k] = sw ? b : a;
+                A[r][k] = sw ? a : b;
+            }
+        }
+#pragma unroll
         for (int r = c + 1; r < 8; ++r) {
             const double f = A[r][c] / A[c][c];
+#pragma unroll
             for (int k = c; k < 9; ++k) A[r][k] = A[r][k] - f * A[c][k];
         }
     }
+#pragma unroll
     for (int r = 7; r >= 0; --r) {
         double s = A[r][8];
+#pragma unroll
         for (int k = r + 1; k < 8; ++k) s = s - A[r][k] * A[k][8];
         A[r][8] = s / A[r][r];
     }
@@ -1283,6 +1307,7 @@ __global__ __launch_bounds__(256) void k_ov_geometry(const Keypoint *__restrict_
             }
         }
         double A[8][9];
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             const double x = s_ox[pick[j]], y = s_oy[pick[j]], X = s_sx[pick[j]], Y = s_sy[pick[j]];
             double *r0 = A[2 * j], *r1 = A[2 * j + 1];
@@ -1291,6 +1316,7 @@ __global__ __launch_bounds__(256) void k_ov_geometry(const Keypoint *__restrict_
         }
         if (!solve8(A)) continue;
         double Hc[9];
+#pragma unroll
         for (int k = 0; k < 8; ++k) Hc[k] = A[k][8];
         Hc[8] = 1.0;
         int cnt = 0;
@@ -1326,6 +1352,7 @@ __global__ __launch_bounds__(256) void k_ov_geometry(const Keypoint *__restrict_
             }
         }
         double A[8][9];
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             const double x = s_ox[pick[j]], y = s_oy[pick[j]], X = s_sx[pick[j]], Y = s_sy[pick[j]];
             double *r0 = A[2 * j], *r1 = A[2 * j + 1];
