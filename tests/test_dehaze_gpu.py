@@ -112,6 +112,24 @@ def test_guided_filter_two_waves_per_strip(ctx, monkeypatch, shape, r):
         assert np.abs(res2 - dz.RC_correction(dz.normalize_input(guide), 15)).max() <= TOL
 
 
+@pytest.mark.parametrize("nw", [2, 4])
+@pytest.mark.parametrize("shape,r", [((200, 1100), 40), ((170, 516), 12), ((330, 1920), 40)])
+def test_guided_filter_final_with_several_waves_per_strip(ctx, monkeypatch, nw, shape, r):
+    """UWIP_GF_FINAL_NW = 2 | 4: k_gf_ws_final with 512- / 1024-column strips (windows that straddle two waves' columns take
+    the left wave's row total; whole waves beyond the image's right edge) -- the plain filter against the oracle, and the
+    dehaze chain, whose first filter is the form with the fused scene recovery (per-block min / max / sum over the waves)."""
+    rng = np.random.default_rng(9)
+    guide = synth.uw_frame(4, *shape)
+    p = rng.random(shape)
+    qo = dz.guided_filter(dz.normalize_input(guide), p, r, 1e-3)
+    monkeypatch.setenv("UWIP_GF_FINAL_NW", str(nw))
+    q = bg.guided_filter(ctx, _dev(guide), _dev(p), r, 1e-3).cpu().numpy()[0]
+    assert np.abs(q - qo).max() <= TOL
+    if r == 40:
+        res = bg.dehaze(ctx, _dev(guide), 15, full=False, want_float=True)["float"].cpu().numpy()[0]
+        assert np.abs(res - dz.RC_correction(dz.normalize_input(guide), 15)).max() <= TOL
+
+
 def test_guided_filter_rejects_large_radius(ctx):
     import uwimageproc_amd as uw
     guide = synth.uw_frame(7, 210, 230)

@@ -313,6 +313,12 @@ __global__ __launch_bounds__(64 * NW) void k_gf_ws_solve(const uint8_t *__restri
 
     const int y0 = by * rpc, y1 = min(H, y0 + rpc);
     const double rdd = 1.0 / (double)(mx - mn);
+    const double rDD = 1.0 / ((double)(2 * r + 1) * (double)(2 * r + 1));
+    bool lane_full = true;
+#pragma unroll
+    for (int j = 0; j < NSC; ++j)
+        if (s_act[j]) lane_full = lane_full && (sx0 + j - r >= 0) && (sx0 + j + r < W);
+    const bool wave_full = __all(lane_full) != 0;      // every solved column's window lies inside the image's columns
     // warm-up: rows [max(0, y0 - r), y0 + r) in batches of four loads
     int v = max(y0 - r, 0);
     const int wend = min(y0 + r, H);   // first row that belongs to the steady loop
@@ -384,10 +390,14 @@ __global__ __launch_bounds__(64 * NW) void k_gf_ws_solve(const uint8_t *__restri
         }
         sync();
 
-        const double cy = count_of(y - r, y + r, H);
+        const int cyi = min(y + r, H - 1) - max(y - r, 0) + 1;
+        const double cy = (double)cyi;
+        // 1 / window size: one reciprocal per row where every window of the wave spans 2r + 1 columns, none where the rows do too
+        double rrow = 0.0;
+        if (wave_full) rrow = cyi == 2 * r + 1 ? rDD : fast_rcp(cy * (double)(2 * r + 1));
         auto solve_col = [&](int j) {
             const int x = sx0 + j;
-            const double rbase = fast_rcp(cy * count_of(x - r, x + r, W));
+            const double rbase = wave_full ? rrow : fast_rcp(cy * count_of(x - r, x + r, W));
             const double r1 = rdd * rbase, r2 = (rdd * rdd) * rbase;
             uint32_t w9[9];
             {
@@ -484,9 +494,10 @@ struct FinalRow {
 
 // REC (bgdehaze's scene recovery fused into the first filter, BGDehaze.py:50-52): instead of q = refined t the kernel
 // writes  J_ip = (normv(I_ip) - B_ip) / q + B_ip  and leaves each wave's min / max / sum of J in `rec.part` -- the separate
-// k_recover pass (read 19 B + write 16 B per pixel) disappears.  Same operations as k_recover, in the same order.
-template <bool VEC, bool REC>
-__global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S /*[Z][4][H][W]*/,
+// k_recover pass (read 19 B + write 16 B per pixel) disappears.  The division by q = X / N is a multiplication by N / X with a
+// Newton reciprocal (within 2 ulp of k_recover's division; compared at 1e-9).
+template <bool VEC, bool REC, int NW>
+__global__ __launch_bounds__(64 * NW) void k_gf_ws_final(const double *__restrict__ S /*[Z][4][H][W]*/,
                                                     const uint8_t *__restrict__ guide, size_t step, size_t fs,
                                                     const int *__restrict__ gnorm, int gnorm_stride, int NP,
                                                     double *__restrict__ Q /*[Z][H][W]*/, int H, int W, int r, int TS,
@@ -494,12 +505,17 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
                                                     uwip_gf_recover rec)
 {
 #pragma clang fp contract(fast)
-    __shared__ double2 s_d2[2 * 4 * 64];
+    static_assert(NW == 1 || VEC, "several waves per strip: aligned path only");
+    __shared__ double2 s_d2[NW * 2 * 4 * 64];
+    __shared__ double s_tot[NW][4];            // row totals of a wave's four planes
     __shared__ double s_nt[REC ? 256 : 1];
+    __shared__ double s_j[REC && NW > 1 ? NW * 3 : 1];
     unsigned bx, by, bz;
     if (!xcd_decode(nb.x, nb.y, nb.z, bx, by, bz)) return;
     StripGeom sg;
-    sg.init(bx, TS, r, W);
+    sg.init(bx, TS, r, W, NW);
+    const int wv = NW > 1 ? (int)(threadIdx.x >> 6) : 0;
+    auto sync = [&]() { if constexpr (NW > 1) __syncthreads(); else wave_lds_fence(); };
     const int l = sg.l, z = bz, f = z / NP;
     const size_t n = (size_t)H * W;
     const int mn = gnorm[(size_t)f * gnorm_stride], mx = gnorm[(size_t)f * gnorm_stride + 1];
@@ -508,16 +524,16 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
     double *jpart = REC ? rec.part + ((size_t)z * nb.x * nb.y + (size_t)by * nb.x + bx) * 3 : nullptr;
     if (REC) {
         Bc = rec.sc[(size_t)f * rec.sc_stride + rec.b_off + ipc];
-        for (int v = l; v < 256; v += 64) s_nt[v] = (double)(v - mn) / (double)(mx - mn);
-        wave_lds_fence();
+        for (int v = (int)threadIdx.x; v < 256; v += 64 * NW) s_nt[v] = (double)(v - mn) / (double)(mx - mn);
+        sync();
     }
     const uint8_t *gf = guide + (size_t)f * fs;
     const double *sp = S + (size_t)z * 4 * n;
     const int D = 2 * r + 1;
     const int s_end = min(min(D, H), (int)(by + 1) * spw);
     int s = by * spw, y = s;
-    if (s >= s_end) {
-        if (REC && l == 0) { jpart[0] = jmin; jpart[1] = jmax; jpart[2] = 0.0; }
+    if (s >= s_end) {       // uniform over the block
+        if (REC && threadIdx.x == 0) { jpart[0] = jmin; jpart[1] = jmax; jpart[2] = 0.0; }
         return;
     }
 
@@ -546,6 +562,13 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
         }
     };
     const double rdd = 1.0 / (double)(mx - mn);
+    const double rDD = 1.0 / ((double)D * (double)D);
+    // every output column of this wave has its whole window inside the image (all strips but the first and the last)
+    bool lane_full = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (sg.act[j]) lane_full = lane_full && (sg.x0 + j - r >= 0) && (sg.x0 + j + r < W);
+    const bool wave_full = __all(lane_full) != 0;
 
     // one link of a chain: `cur` holds S[min(y + r, H - 1)], `prev` holds S[y - r - 1] (zeros above the image).
     // Leaves the next link's rows in (prev := next cur, cur := next prev) -- the caller swaps the two buffers.
@@ -602,27 +625,44 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            s_d2[(0 * 4 + j) * 64 + l] = make_double2(d[0][j], d[1][j]);
-            s_d2[(1 * 4 + j) * 64 + l] = make_double2(d[2][j], d[3][j]);
+            s_d2[wv * 512 + (0 * 4 + j) * 64 + l] = make_double2(d[0][j], d[1][j]);
+            s_d2[wv * 512 + (1 * 4 + j) * 64 + l] = make_double2(d[2][j], d[3][j]);
         }
-        wave_lds_fence();
-        const double cy = count_of(y - r, y + r, H);
+        if (NW > 1 && l == 63) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s_tot[wv][k] = d[k][3];
+        }
+        sync();
+        // window size N = cy * cx: one reciprocal per row where every window of the wave spans 2r + 1 columns, none where the
+        // rows do too; the recovery divides by q = X / N, i.e. multiplies by N / X, and needs no 1 / N at all
+        const int cyi = min(y + r, H - 1) - max(y - r, 0) + 1;
+        const double cy = (double)cyi;
+        double nrow = 0.0;
+        if (REC) nrow = cy * (double)D;
+        else if (wave_full) nrow = cyi == D ? rDD : fast_rcp(cy * (double)D);
         double qv[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (sg.act[j]) {
                 const int x = sg.x0 + j;
-                const double rbase = fast_rcp(cy * count_of(x - r, x + r, W));
-                const double2 hA = s_d2[0 * 256 + sg.ah[j]], hB = s_d2[1 * 256 + sg.ah[j]];
-                double2 lA = s_d2[0 * 256 + sg.al[j]], lB = s_d2[1 * 256 + sg.al[j]];
+                const double2 hA = s_d2[sg.ahw[j] * 512 + 0 * 256 + sg.ah[j]], hB = s_d2[sg.ahw[j] * 512 + 1 * 256 + sg.ah[j]];
+                double2 lA = s_d2[sg.alw[j] * 512 + 0 * 256 + sg.al[j]], lB = s_d2[sg.alw[j] * 512 + 1 * 256 + sg.al[j]];
                 if (!sg.lo_ok[j]) { lA = make_double2(0.0, 0.0); lB = lA; }
-                const double I0 = (double)(byte_of(gw, 3 * j) - mn) * rdd, I1 = (double)(byte_of(gw, 3 * j + 1) - mn) * rdd,
-                             I2 = (double)(byte_of(gw, 3 * j + 2) - mn) * rdd;
-                qv[j] = ((hA.x - lA.x) * I0 + (hA.y - lA.y) * I1 + (hB.x - lB.x) * I2 + (hB.y - lB.y)) * rbase;
+                if (NW > 1 && sg.ahw[j] != sg.alw[j]) {    // the window straddles two waves' columns (2r + 1 <= 256: never three)
+                    const int t = sg.alw[j];
+                    lA.x -= s_tot[t][0]; lA.y -= s_tot[t][1]; lB.x -= s_tot[t][2]; lB.y -= s_tot[t][3];
+                }
+                // X = sum(a) . I + sum(b) with I = u / (mx - mn), u the guide byte above the frame minimum
+                const double u0 = (double)(byte_of(gw, 3 * j) - mn), u1 = (double)(byte_of(gw, 3 * j + 1) - mn),
+                             u2 = (double)(byte_of(gw, 3 * j + 2) - mn);
+                const double X = ((hA.x - lA.x) * u0 + (hA.y - lA.y) * u1 + (hB.x - lB.x) * u2) * rdd + (hB.y - lB.y);
                 if (REC) {
-                    const double jv = (s_nt[byte_of(gw, 3 * j + ipc)] - Bc) / qv[j] + Bc;
+                    const double N = wave_full ? nrow : cy * count_of(x - r, x + r, W);
+                    const double jv = ((s_nt[byte_of(gw, 3 * j + ipc)] - Bc) * N) * fast_rcp(X) + Bc;
                     qv[j] = jv;
                     jmin = fmin(jmin, jv); jmax = fmax(jmax, jv); jsum += jv;
+                } else {
+                    qv[j] = X * (wave_full ? nrow : fast_rcp(cy * count_of(x - r, x + r, W)));
                 }
             }
         }
@@ -637,7 +677,7 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
             for (int j = 0; j < 4; ++j)
                 if (sg.act[j]) o[j] = qv[j];
         }
-        wave_lds_fence();
+        sync();
         y = yn; s = sn;
         return more;
     };
@@ -657,7 +697,17 @@ __global__ __launch_bounds__(64) void k_gf_ws_final(const double *__restrict__ S
             jmax = fmax(jmax, __shfl_xor(jmax, sft, 64));
             jsum += __shfl_xor(jsum, sft, 64);
         }
-        if (l == 0) { jpart[0] = jmin; jpart[1] = jmax; jpart[2] = jsum; }
+        if constexpr (NW > 1) {
+            if (l == 0) { s_j[wv * 3 + 0] = jmin; s_j[wv * 3 + 1] = jmax; s_j[wv * 3 + 2] = jsum; }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int t = 1; t < NW; ++t) {
+                    jmin = fmin(jmin, s_j[t * 3 + 0]); jmax = fmax(jmax, s_j[t * 3 + 1]); jsum += s_j[t * 3 + 2];
+                }
+                jpart[0] = jmin; jpart[1] = jmax; jpart[2] = jsum;
+            }
+        } else if (l == 0) { jpart[0] = jmin; jpart[1] = jmax; jpart[2] = jsum; }
     }
 }
 
@@ -680,8 +730,7 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
     UWIP_REQUIRE(ctx, H >= 2 * r + 1 && W >= 2 * r + 1, "guided filter needs rows, cols >= 2r+1");
     UWIP_REQUIRE(ctx, (uint64_t)uwip_cdiv(W, 256 - 2 * r) * 16 * F * np < (1ull << 31) && (uint64_t)uwip_cdiv(W, 256 - 2 * r) * (2 * r + 1) * F * np < (1ull << 31), "too many blocks for one launch");
     UWIP_REQUIRE(ctx, (uint64_t)256 * (2 * r + 1) * 65025ull < (1ull << 32), "window too large for the exact integer guide sums");
-    const int TS = 256 - 2 * r, D = 2 * r + 1;
-    const unsigned strips = uwip_cdiv(W, TS);
+    const int D = 2 * r + 1;
     // four adjacent columns of a lane are one aligned vector access when everything is a multiple of 4
     const bool vec = (W % 4 == 0) && (r % 4 == 0) && (step % 4 == 0) && (fs % 4 == 0) && (((uintptr_t)guide) % 4 == 0) &&
                      (((uintptr_t)P | (uintptr_t)Q | (uintptr_t)AB) % 16 == 0);
@@ -756,29 +805,45 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
 #undef UWIP_GF_SOLVE
     }
     {
-        // final: chains are independent, so split the 2r+1 chain starts over enough waves for ~4 rounds
+        // final: chains are independent, so split the 2r+1 chain starts over enough waves for ~4 rounds.
+        // NWF waves share a strip of 256 NWF columns (aligned path): the kernel runs at the HBM rate and every strip re-reads
+        // 2r halo columns of S, so wider strips are fewer bytes -- 1920 columns, r = 40: 11 strips read 2720 columns of every
+        // row, 3 strips of 4 waves 2080 (-24 %); lanes beyond the image load nothing.  UWIP_GF_FINAL_NW = 1 | 2 | 4.
         const unsigned Z = (unsigned)F * np;
-        const void *kfinal = rec ? (const void *)k_gf_ws_final<true, true>
-                                 : vec ? (const void *)k_gf_ws_final<true, false> : (const void *)k_gf_ws_final<false, false>;
+        int nwf = 1;
+        if (vec) {
+            const char *e = getenv("UWIP_GF_FINAL_NW");
+            if (e && (atoi(e) == 1 || atoi(e) == 2 || atoi(e) == 4)) nwf = atoi(e);
+        }
+        const int TSf = 256 * nwf - 2 * r;
+        const unsigned strips_f = uwip_cdiv(W, TSf);
+        const void *kfinal = rec ? (nwf == 4 ? (const void *)k_gf_ws_final<true, true, 4> : nwf == 2 ? (const void *)k_gf_ws_final<true, true, 2> : (const void *)k_gf_ws_final<true, true, 1>)
+                           : vec ? (nwf == 4 ? (const void *)k_gf_ws_final<true, false, 4> : nwf == 2 ? (const void *)k_gf_ws_final<true, false, 2> : (const void *)k_gf_ws_final<true, false, 1>)
+                                 : (const void *)k_gf_ws_final<false, false, 1>;
         if (rec) UWIP_REQUIRE(ctx, vec && rec->sc, "fused recovery needs the aligned path");
         const int nchain = std::min(D, H);
-        int groups = (int)std::ceil(4.0 * slots_of(kfinal) / ((double)strips * Z));
+        int groups = (int)std::ceil(4.0 * slots_of(kfinal, 64 * nwf) / ((double)strips_f * Z));
         const char *e = getenv("UWIP_GF_GROUPS");
         if (e && atoi(e) > 0) groups = atoi(e);
         groups = std::max(1, std::min(groups, nchain));
         const int spw = (nchain + groups - 1) / groups;
-        const uint3 nb = make_uint3(strips, uwip_cdiv(nchain, spw), Z);
+        const uint3 nb = make_uint3(strips_f, uwip_cdiv(nchain, spw), Z);
         const unsigned grid = 8u * ((nb.x * nb.y * nb.z + 7u) / 8u);
         uwip_kscope ks(ctx, "k_gf_ws_final");
-        const uwip_gf_recover none{};
+        uwip_gf_recover ra{};
         if (rec) {
-            // one (min, max) pair per block of the launch; the caller reduces them
+            // one (min, max, sum) triple per block of the launch; the caller reduces them
             rec->nb = (int)(nb.x * nb.y);
             rec->part = (double *)uwip_ws(ctx, "gf.jpart", sizeof(double) * 3 * (size_t)rec->nb * Z);
             if (!rec->part) return UWIP_ERR_NOMEM;
-            k_gf_ws_final<true, true><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw, nb, *rec);
-        } else if (vec) k_gf_ws_final<true, false><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw, nb, none);
-        else k_gf_ws_final<false, false><<<grid, 64, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TS, rpc, spw, nb, none);
+            ra = *rec;
+        }
+#define UWIP_GF_FINAL(VECV, RECV, NWV) \
+    k_gf_ws_final<VECV, RECV, NWV><<<grid, 64 * NWV, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TSf, rpc, spw, nb, ra)
+        if (rec) { if (nwf == 4) UWIP_GF_FINAL(true, true, 4); else if (nwf == 2) UWIP_GF_FINAL(true, true, 2); else UWIP_GF_FINAL(true, true, 1); }
+        else if (vec) { if (nwf == 4) UWIP_GF_FINAL(true, false, 4); else if (nwf == 2) UWIP_GF_FINAL(true, false, 2); else UWIP_GF_FINAL(true, false, 1); }
+        else UWIP_GF_FINAL(false, false, 1);
+#undef UWIP_GF_FINAL
     }
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
