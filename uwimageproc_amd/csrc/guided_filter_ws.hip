@@ -754,9 +754,10 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
     // Two waves per strip (512 columns; aligned path only) cover the width with fewer lane-columns -- 1920 columns, r = 40:
     // 5 x 512 against 11 x 256 (-9 %), 3840 columns: 9 x 512 against 22 x 256 (-18 %) -- and measure within 1 % of the
     // one-wave form at 1080p and -4.5 % (solve only) at 4K: the two waves meet at a barrier twice per row and the kernel is
-    // latency-bound per wave, so the saved wave-rows come back as waiting.  Kept for A/B: UWIP_GF_NW=2.
+    // latency-bound per wave, so the saved wave-rows come back as waiting.  Default from 3072 columns up; UWIP_GF_NW = 1 | 2.
     int nw = 1;
     if (vec && 512 - 2 * r > 0) {
+        if (W >= 3072) nw = 2;         // 3840 columns: full pipe 703 -> 707.5 frames/s (same box, twice each)
         const char *e = getenv("UWIP_GF_NW");
         if (e && (atoi(e) == 1 || atoi(e) == 2)) nw = atoi(e);
     }
