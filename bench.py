@@ -110,6 +110,7 @@ def paced_stream(args, dev_index, dev, H, W):
         h_out[-1, -1, -1, :] = (1, 2, 3)                 # no dehazed + stretched frame ends in these bytes twice: proves the D2H landed
         _, t_out = pipe.run_host(h_in, h_out)
         pipe.wait_ticket(t_out)                          # the result is in h_out (the download lane has finished)
+        pipe.ctx.sync()                                  # ... and the batch's overlap ratios are final (they follow the download request)
         finish = time.perf_counter()
         sentinel_ok = sentinel_ok and tuple(h_out[-1, -1, -1, :]) != (1, 2, 3)
         lat += [finish - (t0 + (k + j) / fps) for j in range(B)]

@@ -171,9 +171,10 @@ class FramePipe:
         self._mark("dehaze1")
         self.stage_aclahe()
         self._mark("aclahe1")
+        # the enhanced frames are final here (the overlap stage only reads them): they leave under its kernels
+        h.t_dn[slot] = self.copier.download(h_out, self.work, after=self.ctx)
         self.stage_overlap()
         self._mark("overlap1")
-        h.t_dn[slot] = self.copier.download(h_out, self.work, after=self.ctx)
         h.k = k + 1
         return t_in, h.t_dn[slot]
 
