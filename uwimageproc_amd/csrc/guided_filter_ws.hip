@@ -181,10 +181,11 @@ __global__ __launch_bounds__(64 * NW) void k_gf_ws_solve(const uint8_t *__restri
     const double *pin = P + (size_t)zg * NP * n;
     double p_out = 0.0;         // PU8: p where the window leaves the image
     bool cin[4] = {true, true, true, true};
+    const int ip0 = (zg - f * fdiv) * NP;     // first of this block's p planes inside the frame
     if (PU8) {
         for (int idx = (int)threadIdx.x; idx < NP * 256; idx += 64 * NW) {
             const int ip = idx >> 8, v = idx & 255;
-            const double B = pu8.sc[(size_t)f * pu8.sc_stride + pu8.b_off + ip];
+            const double B = pu8.sc[(size_t)f * pu8.sc_stride + pu8.b_off + ip0 + ip];
             const double q = ((double)(v - mn) / (double)(mx - mn)) / B;
             s_ptab[idx] = fmax(1.0 - q, pu8.tmin);
         }
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(64 * NW) void k_gf_ws_solve(const uint8_t *__restri
         if constexpr (PU8) {
             R.g = *reinterpret_cast<const u32x3 *>(g_lane + (size_t)yy * step);
 #pragma unroll
-            for (int ip = 0; ip < NP; ++ip) R.m[ip] = *reinterpret_cast<const uint32_t *>(m_lane + ((size_t)ip * H + yy) * W);
+            for (int ip = 0; ip < NP; ++ip) R.m[ip] = *reinterpret_cast<const uint32_t *>(m_lane + ((size_t)(ip0 + ip) * H + yy) * W);
         } else if constexpr (VEC) {
             {
                 const uint32_t *q = reinterpret_cast<const uint32_t *>(g_lane + (size_t)yy * step);
@@ -744,11 +745,11 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
         return (double)per_cu * cus;
     };
     const char *env_split = getenv("UWIP_GF_SPLIT");
-    const bool split = !pu8 && np == 2 && env_split && atoi(env_split) > 0;   // two one-plane solves instead of a fused one
+    const bool split = np == 2 && env_split && atoi(env_split) > 0;   // two one-plane solves instead of a fused one
     const int knp = split ? 1 : np;
     const unsigned zs = (unsigned)F * (np / knp);
     // (occupancy query only: the 3-column and 4-column solve mappings differ by a few registers, both one wave per SIMD)
-    const void *ksolve = pu8 ? (const void *)k_gf_ws_solve<2, true, true, true, 1>
+    const void *ksolve = pu8 ? (knp == 2 ? (const void *)k_gf_ws_solve<2, true, true, true, 1> : (const void *)k_gf_ws_solve<1, true, true, true, 1>)
                        : knp == 2 ? (vec ? (const void *)k_gf_ws_solve<2, true, false, true, 1> : (const void *)k_gf_ws_solve<2, false, false, true, 1>)
                                   : (vec ? (const void *)k_gf_ws_solve<1, true, false, true, 1> : (const void *)k_gf_ws_solve<1, false, false, true, 1>);
     // Two waves per strip (512 columns; aligned path only) cover the width with fewer lane-columns -- 1920 columns, r = 40:
@@ -794,7 +795,9 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
     k_gf_ws_solve<NPV, VECV, PU8V, C3V, NWV><<<grid, 64 * NWV, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, \
                                                                                TSs, rpc, fdiv, nb, pa)
         const bool c3 = nw == 1 && TSs <= 192;
-        if (pu8) {
+        if (pu8 && knp == 1) {
+            if (nw == 2) UWIP_GF_SOLVE(1, true, true, false, 2); else if (c3) UWIP_GF_SOLVE(1, true, true, true, 1); else UWIP_GF_SOLVE(1, true, true, false, 1);
+        } else if (pu8) {
             if (nw == 2) UWIP_GF_SOLVE(2, true, true, false, 2); else if (c3) UWIP_GF_SOLVE(2, true, true, true, 1); else UWIP_GF_SOLVE(2, true, true, false, 1);
         } else if (knp == 2) {
             if (vec) { if (nw == 2) UWIP_GF_SOLVE(2, true, false, false, 2); else if (c3) UWIP_GF_SOLVE(2, true, false, true, 1); else UWIP_GF_SOLVE(2, true, false, false, 1); }
