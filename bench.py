@@ -192,15 +192,19 @@ def cpu_baseline(H, W):
     except (ValueError, OSError):
         free_gb = 64.0
     n = max(1, min(cores, int(np.ceil(quota)) if quota else cores, 256, int(free_gb / 2 / 0.7)))
-    t1 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=n) as ex:
-        list(ex.map(one_frame, range(1, n + 1)))
-    wall = time.perf_counter() - t1
+    # two passes, the better one counts: the host is shared, and one pass in some dozens has come out 2-3x slow
+    walls = []
+    for _ in range(2):
+        t1 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=n) as ex:
+            list(ex.map(one_frame, range(1, n + 1)))
+        walls.append(time.perf_counter() - t1)
+    wall = min(walls)
     return {"value": n / wall, "unit": "frames/s", "cores": n, "cores_visible": cores, "cgroup_cpu_quota": quota, "kind": "port",
             "sample": f"{n} frames of {W}x{H}, one per host thread ({cores} CPUs in the affinity mask, cgroup quota "
-                      f"{quota if quota else 'none'}), whole pipe in C ({build}); single thread: 1 frame",
+                      f"{quota if quota else 'none'}), whole pipe in C ({build}), best of two passes; single thread: 1 frame",
             "single_thread": {"value": 1.0 / single, "unit": "frames/s", "cores": 1, "seconds_per_frame": single, "parts": parts},
-            "all_cores_wall_s": wall, "total_cpu_baseline_s": time.perf_counter() - t0}
+            "all_cores_wall_s": wall, "all_cores_walls_s": walls, "total_cpu_baseline_s": time.perf_counter() - t0}
 
 
 I8_MFMA_PEAK_TOPS = 5000.0     # dense i8 = 2x the ~2.5 PFLOP/s dense BF16 rate (MI355X_MICROARCH.md, Matrix cores)
