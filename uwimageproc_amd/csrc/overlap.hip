@@ -135,23 +135,37 @@ __global__ void k_ov_gray_to_L0(const uint8_t *__restrict__ gray, float *__restr
 // along y out of it.  Every output goes through the same multiplies and adds in the same order as the two-pass form
 // (the intermediate row of image row reflect101(y) is what the y pass of the two-pass form reads there).
 constexpr int CV_TW = 64, CV_TH = 16, CV_RMAX = 7;
+// KS = the kernel size when it is one of the usual ones (5 for sigma 1, 9 for sigma 1.6: loops unrolled, the staging index a
+// constant division), 0 = any odd size up to 2 CV_RMAX + 1 at run time.
+template <int KS>
 __global__ __launch_bounds__(256) void k_ov_conv2(const float *__restrict__ in, float *__restrict__ out, int h, int w, ConvK K)
 {
     __shared__ float s_in[(CV_TH + 2 * CV_RMAX) * (CV_TW + 2 * CV_RMAX)];
     __shared__ float s_tmp[(CV_TH + 2 * CV_RMAX) * CV_TW];
     const int f = blockIdx.z, x0 = blockIdx.x * CV_TW, y0 = blockIdx.y * CV_TH;
     const float *I = in + (size_t)f * h * w;
-    const int r = K.ks / 2, RW = CV_TW + 2 * r, RH = CV_TH + 2 * r;
-    for (int i = threadIdx.x; i < RH * RW; i += 256) {
-        const int ry = i / RW, rx = i - ry * RW;
-        s_in[i] = I[(size_t)reflect101(y0 - r + ry, h) * w + reflect101(x0 - r + rx, w)];
+    const int ks = KS ? KS : K.ks;
+    const int r = ks / 2, RW = CV_TW + 2 * r, RH = CV_TH + 2 * r;
+    const bool inside = x0 - r >= 0 && y0 - r >= 0 && x0 - r + RW <= w && y0 - r + RH <= h;     // block-uniform
+    if (inside) {
+        const float *base = I + (size_t)(y0 - r) * w + (x0 - r);
+        for (int i = threadIdx.x; i < RH * RW; i += 256) {
+            const int ry = i / RW, rx = i - ry * RW;
+            s_in[i] = base[(size_t)ry * w + rx];
+        }
+    } else {
+        for (int i = threadIdx.x; i < RH * RW; i += 256) {
+            const int ry = i / RW, rx = i - ry * RW;
+            s_in[i] = I[(size_t)reflect101(y0 - r + ry, h) * w + reflect101(x0 - r + rx, w)];
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < RH * CV_TW; i += 256) {
         const int ry = i / CV_TW, tx = i - ry * CV_TW;
         const float *row = s_in + ry * RW + tx;
         float acc = 0.0f;
-        for (int k = 0; k < K.ks; ++k) acc = acc + K.k[k] * row[k];
+#pragma unroll
+        for (int k = 0; k < ks; ++k) acc = acc + K.k[k] * row[k];
         s_tmp[i] = acc;
     }
     __syncthreads();
@@ -159,15 +173,30 @@ __global__ __launch_bounds__(256) void k_ov_conv2(const float *__restrict__ in, 
         const int ty = i / CV_TW, tx = i - ty * CV_TW;
         const float *col = s_tmp + ty * CV_TW + tx;
         float acc = 0.0f;
-        for (int k = 0; k < K.ks; ++k) acc = acc + K.k[k] * col[k * CV_TW];
+#pragma unroll
+        for (int k = 0; k < ks; ++k) acc = acc + K.k[k] * col[k * CV_TW];
         const int x = x0 + tx, y = y0 + ty;
         if (x < w && y < h) out[((size_t)f * h + y) * w + x] = acc;
     }
 }
+template <class... A>
+static void launch_conv2(int ks, dim3 grid, hipStream_t st, A... a)
+{
+    switch (ks) {
+    case 5: k_ov_conv2<5><<<grid, 256, 0, st>>>(a...); break;
+    case 7: k_ov_conv2<7><<<grid, 256, 0, st>>>(a...); break;
+    case 9: k_ov_conv2<9><<<grid, 256, 0, st>>>(a...); break;
+    case 11: k_ov_conv2<11><<<grid, 256, 0, st>>>(a...); break;
+    default: k_ov_conv2<0><<<grid, 256, 0, st>>>(a...); break;
+    }
+}
 
+// INSIDE: the caller knows that the 3 x 3 neighbourhood lies in the image (block-uniform test): no border rule
+template <bool INSIDE = false>
 __device__ __forceinline__ void scharr_at(const float *I, int h, int w, int y, int x, float &gx, float &gy)
 {
-    const int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h), xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+    const int ym = INSIDE ? y - 1 : reflect101(y - 1, h), yp = INSIDE ? y + 1 : reflect101(y + 1, h),
+              xm = INSIDE ? x - 1 : reflect101(x - 1, w), xp = INSIDE ? x + 1 : reflect101(x + 1, w);
     const float a0 = I[(size_t)ym * w + xm], a1 = I[(size_t)ym * w + x], a2 = I[(size_t)ym * w + xp];
     const float b0 = I[(size_t)y * w + xm], b2 = I[(size_t)y * w + xp];
     const float c0 = I[(size_t)yp * w + xm], c1 = I[(size_t)yp * w + x], c2 = I[(size_t)yp * w + xp];
@@ -195,7 +224,7 @@ __global__ __launch_bounds__(256) void k_ov_kc(const float *__restrict__ Lsm, in
     float m = 0.0f;
     if (in) {
         float gx, gy;
-        scharr_at(I, h, w, y, x, gx, gy);
+        scharr_at<true>(I, h, w, y, x, gx, gy);      // in: x +- 1, y +- 1 are pixels of the image
         m = sqrtf(gx * gx + gy * gy);
     }
     if (PASS == 0) {
@@ -353,10 +382,22 @@ __global__ __launch_bounds__(256) void k_ov_fedn(const float *__restrict__ Lin, 
     }
     __syncthreads();
     float *src = s_A, *dst = s_B;
+    // a plane that lies inside the image (three tiles in four at 640 x 360) needs no border rule: neighbours are +-1, +-W2
+    const bool inside = x0 >= 0 && y0 >= 0 && x0 + W2 <= w && y0 + H2 <= h;      // block-uniform
 #pragma unroll
     for (int k = 1; k <= NS; ++k) {
         const float step = 0.5f * taus.t[k - 1];
         const int RW = W2 - 2 * k, RH = H2 - 2 * k;          // region of this step: plane coordinates [k, W2 - k) x [k, H2 - k)
+        if (inside) {
+            for (int i = threadIdx.x; i < RH * RW; i += 256) {
+                const int q = i / RW;
+                const int o = (q + k) * W2 + (i - q * RW) + k;
+                const float v = fed_px(src[o], src[o - 1], src[o + 1], src[o - W2], src[o + W2], s_c[o], s_c[o - 1], s_c[o + 1],
+                                       s_c[o - W2], s_c[o + W2], step);
+                if (k < NS) dst[o] = v;
+                else out[((size_t)f * h + (y0 + q + k)) * w + x0 + (i - q * RW) + k] = v;
+            }
+        } else
         for (int i = threadIdx.x; i < RH * RW; i += 256) {
             const int ry = i / RW + k, rx = i - (i / RW) * RW + k;
             const int x = x0 + rx, y = y0 + ry;
@@ -379,13 +420,14 @@ __global__ __launch_bounds__(256) void k_ov_fedn(const float *__restrict__ Lin, 
 }
 
 // ---- scale-s first derivative (taps at -s, 0, +s) ------------------------------------------------
+template <bool INSIDE = false>
 __device__ __forceinline__ float deriv_at(const float *I, int h, int w, int y, int x, int s, bool along_x)
 {
     const float wgt = 10.0f / 3.0f;
     const float norm = 1.0f / (2.0f * (float)s * (wgt + 2.0f));
     const float wn = wgt * norm;
-    const int ym = reflect101(y - s, h), yp = reflect101(y + s, h);
-    const int xm = reflect101(x - s, w), xp = reflect101(x + s, w);
+    const int ym = INSIDE ? y - s : reflect101(y - s, h), yp = INSIDE ? y + s : reflect101(y + s, h);
+    const int xm = INSIDE ? x - s : reflect101(x - s, w), xp = INSIDE ? x + s : reflect101(x + s, w);
     float t0, t1, t2;
     if (along_x) {
         t0 = norm * (I[(size_t)ym * w + xp] - I[(size_t)ym * w + xm]);
@@ -409,13 +451,22 @@ __global__ __launch_bounds__(256) void k_ov_deriv1(const float *__restrict__ Lsm
     if (x >= w || y >= h) return;
     const float *I = Lsm + (size_t)f * h * w;
     const size_t o = ((size_t)f * h + y) * w + x;
-    Lx[o] = deriv_at(I, h, w, y, x, s, true);
-    Ly[o] = deriv_at(I, h, w, y, x, s, false);
+    // block-uniform: every tap of the block's 64 x 4 pixels lies in the image (s >= 1 covers the Scharr taps too)
+    const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * 4;
+    const bool inside = bx0 - s >= 0 && bx0 + 63 + s < w && by0 - s >= 0 && by0 + 3 + s < h;
+    float gx, gy;
+    if (inside) {
+        Lx[o] = deriv_at<true>(I, h, w, y, x, s, true);
+        Ly[o] = deriv_at<true>(I, h, w, y, x, s, false);
+        if (flow) scharr_at<true>(I, h, w, y, x, gx, gy);
+    } else {
+        Lx[o] = deriv_at(I, h, w, y, x, s, true);
+        Ly[o] = deriv_at(I, h, w, y, x, s, false);
+        if (flow) scharr_at(I, h, w, y, x, gx, gy);
+    }
     if (flow) {
         const float k = kc[f];
         const float inv_k = 1.0f / (k * k);
-        float gx, gy;
-        scharr_at(I, h, w, y, x, gx, gy);
         flow[o] = 1.0f / (1.0f + (gx * gx + gy * gy) * inv_k);
     }
 }
@@ -426,9 +477,18 @@ __global__ __launch_bounds__(256) void k_ov_ldet(const float *__restrict__ Lx, c
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const float *X = Lx + (size_t)f * h * w, *Y = Ly + (size_t)f * h * w;
-    const float lxx = deriv_at(X, h, w, y, x, s, true);
-    const float lyy = deriv_at(Y, h, w, y, x, s, false);
-    const float lxy = deriv_at(X, h, w, y, x, s, false);
+    const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * 4;
+    const bool inside = bx0 - s >= 0 && bx0 + 63 + s < w && by0 - s >= 0 && by0 + 3 + s < h;     // block-uniform
+    float lxx, lyy, lxy;
+    if (inside) {
+        lxx = deriv_at<true>(X, h, w, y, x, s, true);
+        lyy = deriv_at<true>(Y, h, w, y, x, s, false);
+        lxy = deriv_at<true>(X, h, w, y, x, s, false);
+    } else {
+        lxx = deriv_at(X, h, w, y, x, s, true);
+        lyy = deriv_at(Y, h, w, y, x, s, false);
+        lxy = deriv_at(X, h, w, y, x, s, false);
+    }
     const float ss = (float)(s * s), s4 = ss * ss;
     Ldet[((size_t)f * h + y) * w + x] = (lxx * lyy - lxy * lxy) * s4;
 }
@@ -1601,10 +1661,10 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
         const ConvK K0 = gauss_kernel(H_SIGMA[0]), K1 = gauss_kernel(1.0f);
         UWIP_REQUIRE(ctx, K0.ks / 2 <= CV_RMAX && K1.ks / 2 <= CV_RMAX && (K0.ks & 1) && (K1.ks & 1), "Gaussian kernel too wide for k_ov_conv2");
         const dim3 gc(uwip_cdiv(w, CV_TW), uwip_cdiv(h, CV_TH), (unsigned)F);
-        k_ov_conv2<<<gc, 256, 0, ctx->stream>>>(W.L0, W.Lt, h, w, K0);
+        launch_conv2(K0.ks, gc, ctx->stream, (const float *)W.L0, W.Lt, h, w, K0);
         for (int lv = 0; lv < NLEV; ++lv) {
             float *Lt = W.Lt + lv * lvl;
-            k_ov_conv2<<<gc, 256, 0, ctx->stream>>>(Lt, W.Lsm, h, w, K1);
+            launch_conv2(K1.ks, gc, ctx->stream, (const float *)Lt, W.Lsm, h, w, K1);
             if (lv == 0) {
                 const int nbk = (int)(g.x * g.y);
                 uint32_t *kpart = (uint32_t *)uwip_ws(ctx, "ov.kcpart", sizeof(uint32_t) * nbk * F);
