@@ -498,61 +498,85 @@ __global__ __launch_bounds__(256) void k_ov_ldet(const float *__restrict__ Lx, c
 // The detector threshold is relative to the frame's contrast factor k (det of the Hessian scales with contrast squared;
 // raw frames of turbid water have no response above a fixed 1e-3): DTHRESH * min(1, (k / KC_REF)^2), in the oracle's
 // operations; `fixed` keeps DTHRESH (UWIP_OVERLAP_FIXED_THRESHOLD).
+// One block = a 64 x 8 tile of ALL levels: the four level tiles + 1 halo pixel are staged in LDS once (coalesced rows), and
+// every comparison of the 3 x 3 x 3 test and the sub-pixel check reads LDS -- the dense map of every level is read once
+// (x 1.29 for the halo) instead of once plus 26 scattered neighbour loads wherever any lane of a wave passes the threshold.
+constexpr int EX_TW = 64, EX_TH = 8, EX_PW = EX_TW + 2, EX_PH = EX_TH + 2;
 __global__ __launch_bounds__(256) void k_ov_extrema(const float *__restrict__ Ldet, float *__restrict__ cand, int h, int w, int F,
                                                    const float *__restrict__ kc, int fixed, uint32_t *__restrict__ selhist)
 {
-    const int f = blockIdx.z / NLEV, lv = blockIdx.z % NLEV;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= w || y >= h) return;
+    __shared__ float s_D[NLEV][EX_PH * EX_PW];
+    const int f = blockIdx.z, x0 = blockIdx.x * EX_TW, y0 = blockIdx.y * EX_TH;
     const size_t n = (size_t)h * w;
-    const float *D = Ldet + ((size_t)lv * F + f) * n;
-    float out = 0.0f;
-    if (x >= BORDER && x < w - BORDER && y >= BORDER && y < h - BORDER) {
-        const float v = D[(size_t)y * w + x];
-        const float kr = kc[f] / KC_REF;
-        float ks = kr * kr;
-        if (!(ks < 1.0f)) ks = 1.0f;
-        const float dthr = fixed ? DTHRESH : DTHRESH * ks;
-        bool ok = v > dthr;
-        if (ok) {
+    for (int i = threadIdx.x; i < EX_PH * EX_PW; i += 256) {
+        const int ry = i / EX_PW, rx = i - ry * EX_PW;
+        const int gy = y0 - 1 + ry, gx = x0 - 1 + rx;
+        const bool in = gy >= 0 && gy < h && gx >= 0 && gx < w;       // positions outside are never compared (BORDER >= 1)
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
+        for (int lv = 0; lv < NLEV; ++lv) s_D[lv][i] = in ? Ldet[((size_t)lv * F + f) * n + (size_t)gy * w + gx] : 0.0f;
+    }
+    __syncthreads();
+    const float kr = kc[f] / KC_REF;
+    float ks = kr * kr;
+    if (!(ks < 1.0f)) ks = 1.0f;
+    const float dthr = fixed ? DTHRESH : DTHRESH * ks;
+    const int tx = threadIdx.x & 63, x = x0 + tx;
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx)
-                    if ((dx != 0 || dy != 0) && !(v > D[(size_t)(y + dy) * w + x + dx])) ok = false;
-        }
-        for (int o = -1; o <= 1 && ok; o += 2) {
-            const int l2 = lv + o;
-            if (l2 < 0 || l2 >= NLEV) continue;
-            const float *E = Ldet + ((size_t)l2 * F + f) * n;
-            for (int dy = -1; dy <= 1; ++dy)
-                for (int dx = -1; dx <= 1; ++dx)
-                    if (!(v > E[(size_t)(y + dy) * w + x + dx])) ok = false;
-        }
-        if (ok) {
-            // candidates that the sub-pixel refinement would discard are dropped here, so that
-            // the top-K selection sees exactly the oracle's candidate list
-            const float vxp = D[(size_t)y * w + x + 1], vxm = D[(size_t)y * w + x - 1];
-            const float vyp = D[(size_t)(y + 1) * w + x], vym = D[(size_t)(y - 1) * w + x];
-            const float Dx = 0.5f * (vxp - vxm), Dy = 0.5f * (vyp - vym);
-            const float Dxx = (vxp + vxm) - 2.0f * v, Dyy = (vyp + vym) - 2.0f * v;
-            const float Dxy = 0.25f * (D[(size_t)(y + 1) * w + x + 1] + D[(size_t)(y - 1) * w + x - 1]) -
-                              0.25f * (D[(size_t)(y + 1) * w + x - 1] + D[(size_t)(y - 1) * w + x + 1]);
-            const float det = Dxx * Dyy - Dxy * Dxy;
-            if (det == 0.0f) ok = false;
-            else {
-                const float ox = -(Dyy * Dx - Dxy * Dy) / det, oy = -(Dxx * Dy - Dxy * Dx) / det;
-                if (!(fabsf(ox) <= 1.0f && fabsf(oy) <= 1.0f)) ok = false;
+    for (int k = 0; k < EX_TH / 4; ++k) {
+        const int ty = (threadIdx.x >> 6) + 4 * k, y = y0 + ty;
+        if (x >= w || y >= h) continue;
+        const bool inb = x >= BORDER && x < w - BORDER && y >= BORDER && y < h - BORDER;
+        const int c = (ty + 1) * EX_PW + tx + 1;
+#pragma unroll
+        for (int lv = 0; lv < NLEV; ++lv) {
+            const float *D = s_D[lv];
+            float out = 0.0f;
+            const float v = D[c];
+            bool ok = inb && v > dthr;
+            if (ok) {
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                    for (int dx = -1; dx <= 1; ++dx)
+                        if ((dx != 0 || dy != 0) && !(v > D[c + dy * EX_PW + dx])) ok = false;
             }
             if (ok) {
-                out = v;
-                // first pass of the top-K radix select (k_ov_sel_hist<0>'s histogram of the high 16 response bits) counted here:
-                // candidates are a few thousand per frame, and the dense map is read once less
-                atomicAdd(&selhist[(size_t)f * 65536 + (__float_as_uint(v) >> 16)], 1u);
+#pragma unroll
+                for (int o = -1; o <= 1; o += 2) {
+                    const int l2 = lv + o;
+                    if (l2 < 0 || l2 >= NLEV) continue;
+                    const float *E = s_D[l2];
+#pragma unroll
+                    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; ++dx)
+                            if (!(v > E[c + dy * EX_PW + dx])) ok = false;
+                }
             }
+            if (ok) {
+                // candidates that the sub-pixel refinement would discard are dropped here, so that
+                // the top-K selection sees exactly the oracle's candidate list
+                const float vxp = D[c + 1], vxm = D[c - 1];
+                const float vyp = D[c + EX_PW], vym = D[c - EX_PW];
+                const float Dx = 0.5f * (vxp - vxm), Dy = 0.5f * (vyp - vym);
+                const float Dxx = (vxp + vxm) - 2.0f * v, Dyy = (vyp + vym) - 2.0f * v;
+                const float Dxy = 0.25f * (D[c + EX_PW + 1] + D[c - EX_PW - 1]) - 0.25f * (D[c + EX_PW - 1] + D[c - EX_PW + 1]);
+                const float det = Dxx * Dyy - Dxy * Dxy;
+                if (det == 0.0f) ok = false;
+                else {
+                    const float ox = -(Dyy * Dx - Dxy * Dy) / det, oy = -(Dxx * Dy - Dxy * Dx) / det;
+                    if (!(fabsf(ox) <= 1.0f && fabsf(oy) <= 1.0f)) ok = false;
+                }
+                if (ok) {
+                    out = v;
+                    // first pass of the top-K radix select (k_ov_sel_hist<0>'s histogram of the high 16 response bits) counted
+                    // here: candidates are a few thousand per frame, and the dense map is read once less
+                    atomicAdd(&selhist[(size_t)f * 65536 + (__float_as_uint(v) >> 16)], 1u);
+                }
+            }
+            cand[((size_t)f * NLEV + lv) * n + (size_t)y * w + x] = out;
         }
     }
-    cand[((size_t)f * NLEV + lv) * n + (size_t)y * w + x] = out;
 }
 
 // ---- top-K selection: 2-pass radix select on the float bit patterns ---------------------------------
@@ -612,23 +636,26 @@ __global__ __launch_bounds__(256) void k_ov_sel_pick(const uint32_t *__restrict_
 
 // ---- ordered compaction + sub-pixel refinement ---------------------------------------------------------
 constexpr int CMP_CHUNK = 1024;
+// One WAVE per chunk of CMP_CHUNK map entries (ballot + popcount: no LDS, no barrier)
 __global__ __launch_bounds__(256) void k_ov_count(const float *__restrict__ cand, size_t n4, const uint32_t *__restrict__ sel,
                                                  uint32_t *__restrict__ counts, int nchunks)
 {
-    __shared__ uint32_t scratch[8];
-    const int f = blockIdx.y, ch = blockIdx.x;
+    const int f = blockIdx.y, ch = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ch >= nchunks) return;
     const uint32_t thr = sel[(size_t)f * 4 + 3];
     const float *c = cand + (size_t)f * n4;
-    uint32_t m = 0;
-    for (int k = 0; k < CMP_CHUNK / 256; ++k) {
-        const size_t i = (size_t)ch * CMP_CHUNK + (size_t)k * 256 + threadIdx.x;
+    uint32_t tot = 0;
+#pragma unroll 4
+    for (int k = 0; k < CMP_CHUNK / 64; ++k) {
+        const size_t i = (size_t)ch * CMP_CHUNK + (size_t)k * 64 + lane;
+        bool flag = false;
         if (i < n4) {
             const uint32_t b = __float_as_uint(c[i]);
-            m += (b != 0 && b >= thr) ? 1u : 0u;
+            flag = b != 0 && b >= thr;
         }
+        tot += (uint32_t)__popcll(__ballot(flag));
     }
-    const uint32_t tot = block256_sum_u32(m, scratch);
-    if (threadIdx.x == 0) counts[(size_t)f * nchunks + ch] = tot;
+    if (lane == 0) counts[(size_t)f * nchunks + ch] = tot;
 }
 
 __global__ __launch_bounds__(256) void k_ov_scan_chunks(uint32_t *__restrict__ counts, int nchunks, int32_t *__restrict__ nkp)
@@ -656,26 +683,24 @@ __global__ __launch_bounds__(256) void k_ov_compact(const float *__restrict__ ca
                                                    const uint32_t *__restrict__ sel, const uint32_t *__restrict__ offsets,
                                                    int nchunks, Keypoint *__restrict__ kps, int F)
 {
-    __shared__ uint32_t scratch[8];
-    __shared__ uint32_t s_base;
-    const int f = blockIdx.y, ch = blockIdx.x;
+    const int f = blockIdx.y, ch = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ch >= nchunks) return;
     const size_t n = (size_t)h * w, n4 = n * NLEV;
     const uint32_t thr = sel[(size_t)f * 4 + 3];
     const float *c = cand + (size_t)f * n4;
-    if (threadIdx.x == 0) s_base = offsets[(size_t)f * nchunks + ch];
-    __syncthreads();
-    for (int k = 0; k < CMP_CHUNK / 256; ++k) {
-        const size_t i = (size_t)ch * CMP_CHUNK + (size_t)k * 256 + threadIdx.x;
-        uint32_t flag = 0;
+    uint32_t base = offsets[(size_t)f * nchunks + ch];          // wave-uniform: entries selected before this chunk
+    for (int k = 0; k < CMP_CHUNK / 64 && base < (uint32_t)MAXKP; ++k) {
+        const size_t i = (size_t)ch * CMP_CHUNK + (size_t)k * 64 + lane;
+        bool flag = false;
         float v = 0.0f;
         if (i < n4) {
             v = c[i];
             const uint32_t b = __float_as_uint(v);
-            flag = (b != 0 && b >= thr) ? 1u : 0u;
+            flag = b != 0 && b >= thr;
         }
-        const uint32_t incl = block256_incl_scan_u32(flag, scratch);
-        const uint32_t base = s_base;
-        const uint32_t pos = base + incl - flag;
+        const unsigned long long mask = __ballot(flag);
+        const uint32_t pos = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        base += (uint32_t)__popcll(mask);
         if (flag && pos < (uint32_t)MAXKP) {
             const int lv = (int)(i / n);
             const size_t r = i - (size_t)lv * n;
@@ -694,9 +719,6 @@ __global__ __launch_bounds__(256) void k_ov_compact(const float *__restrict__ ca
             kp.level = lv; kp.xi = x; kp.yi = y; kp.co = 1.0f; kp.si = 0.0f;
             kps[(size_t)f * MAXKP + pos] = kp;
         }
-        __syncthreads();
-        if (threadIdx.x == 255) s_base = base + incl;
-        __syncthreads();
     }
 }
 
@@ -1713,14 +1735,14 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
     {
         uwip_kscope ks(ctx, "k_ov_detect");
         UWIP_HIP(ctx, hipMemsetAsync(W.selhist, 0, sizeof(uint32_t) * 65536 * F, ctx->stream));
-        k_ov_extrema<<<grid2d(w, h, F * NLEV), 256, 0, ctx->stream>>>(W.Ldet, W.cand, h, w, F, W.kc, fixed_thr, W.selhist);
+        k_ov_extrema<<<dim3(uwip_cdiv(w, EX_TW), uwip_cdiv(h, EX_TH), (unsigned)F), 256, 0, ctx->stream>>>(W.Ldet, W.cand, h, w, F, W.kc, fixed_thr, W.selhist);
         k_ov_sel_pick<0><<<F, 256, 0, ctx->stream>>>(W.selhist, W.sel);
         UWIP_HIP(ctx, hipMemsetAsync(W.selhist, 0, sizeof(uint32_t) * 65536 * F, ctx->stream));
         k_ov_sel_hist<1><<<dim3(64, F), 256, 0, ctx->stream>>>(W.cand, n4, W.selhist, W.sel);
         k_ov_sel_pick<1><<<F, 256, 0, ctx->stream>>>(W.selhist, W.sel);
-        k_ov_count<<<dim3(nchunks, F), 256, 0, ctx->stream>>>(W.cand, n4, W.sel, W.counts, nchunks);
+        k_ov_count<<<dim3(uwip_cdiv(nchunks, 4), F), 256, 0, ctx->stream>>>(W.cand, n4, W.sel, W.counts, nchunks);
         k_ov_scan_chunks<<<F, 256, 0, ctx->stream>>>(W.counts, nchunks, nkp);
-        k_ov_compact<<<dim3(nchunks, F), 256, 0, ctx->stream>>>(W.cand, W.Ldet, h, w, W.sel, W.counts, nchunks, kps, F);
+        k_ov_compact<<<dim3(uwip_cdiv(nchunks, 4), F), 256, 0, ctx->stream>>>(W.cand, W.Ldet, h, w, W.sel, W.counts, nchunks, kps, F);
         UWIP_HIP(ctx, hipGetLastError());
     }
     {
