@@ -10,8 +10,9 @@
 //     and every output column taking  G[x+r] - G[x-r-1];
 //   * k_gf_ws_solve inverts the 3x3 (cov(I) + eps) per pixel and writes a (3 planes) and b; k_gf_ws_final
 //     box-filters a, b the same way and writes q = mean_a . I + mean_b.
-// A block is a single wave, so there is no workgroup barrier anywhere; the LDS row is private to the wave and
-// LDS operations of one wave execute in order.  Columns outside the image contribute zeros and every mean
+// By default a block is a single wave, so there is no workgroup barrier anywhere; the LDS row is private to the wave and
+// LDS operations of one wave execute in order.  (Optional forms share a strip of 512 / 1024 columns between 2 / 4 waves:
+// template parameter NW of both kernels, selected by UWIP_GF_NW / UWIP_GF_FINAL_NW; DESIGN.md section 5 has the measurements.)  Columns outside the image contribute zeros and every mean
 // divides by the analytic in-image window size, as guidedfilter.py:39-41,67 does.
 //
 // The guide statistics are exact: with I = (v - mn) / (mx - mn) for 8-bit v, the window sums of I and I*I' are
