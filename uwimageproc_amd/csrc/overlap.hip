@@ -243,11 +243,11 @@ __global__ __launch_bounds__(256) void k_ov_kc(const float *__restrict__ Lsm, in
         if (in && m != 0.0f && hmax != 0.0f) {
             int nbin = (int)floorf(300.0f * (m / hmax));
             if (nbin >= 300) nbin = 299;
-            atomicAdd(&s_hist[nbin], 1u);
-            atomicAdd(&s_hist[300], 1u);       // npoints
+            atomicAdd(&s_hist[nbin], 1u);      // npoints = the sum of the bins (k_ov_kc_final): a counter word of its own
+                                               // would take every lane of every wave through one LDS address
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 301; i += 256)
+        for (int i = threadIdx.x; i < 300; i += 256)
             if (s_hist[i]) atomicAdd(&hist[(size_t)f * 304 + i], s_hist[i]);
     }
 }
@@ -272,7 +272,8 @@ __global__ void k_ov_kc_final(const uint32_t *__restrict__ hmax_bits, const uint
     const float hmax = __uint_as_float(hmax_bits[f]);
     if (hmax == 0.0f) { kc[f] = 0.03f; return; }
     const uint32_t *hh = hist + (size_t)f * 304;
-    const int npoints = (int)hh[300];
+    int npoints = 0;
+    for (int k = 0; k < 300; ++k) npoints += (int)hh[k];
     const int nthreshold = (int)((float)npoints * 0.7f);
     int k = 0, nelements = 0;
     for (k = 0; nelements < nthreshold && k < 300; k++) nelements += (int)hh[k];
