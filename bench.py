@@ -397,6 +397,13 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
                                  "the kernel's mix also holds v_cvt_f32_ubyte / v_cvt_pk_u8_f32 / v_lshl_add at 1.83 ns, so "
                                  "mean_ns_per_instr_per_simd against 1.14 .. 1.83 says how busy the issue port is; spec_peak = one "
                                  "wave64 f32 instruction per 2 clocks at 2.4 GHz (128 FMA lanes per CU and clock)"}
+    if e is not None and e.get("lds_idx_active_per_frame"):
+        # the LDS pipe of a CU beside the issue ports: SQ_LDS_IDX_ACTIVE summed over the 256 CUs, 2.4 GHz
+        cyc_cu = e["lds_idx_active_per_frame"] * Fs / 256.0
+        dom["lds"] = {"idx_active_cycles_per_cu_per_launch": cyc_cu, "busy_frac": cyc_cu / ((dms / dcnt) * 1e-3 * 2.4e9),
+                      "bank_conflict_frac_of_active": e.get("lds_bank_conflict_per_frame", 0.0) / e["lds_idx_active_per_frame"],
+                      "source": "SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT of the committed --pmc pass, time from this run: the histogram "
+                                "atomics (neighbouring pixels share bins) keep the LDS pipe about as busy as the VALU ports"}
     roof["dominant"] = dom
     # (3) per stage: kernel time against the stage's 8(d) algorithmic bytes
     stages = {}
