@@ -798,8 +798,25 @@ static __device__ const signed char D_DISC[109][2] = {
     {5, 3},
 };
 /* ORIENT-TABLES-END */
-// lanes 0..28 each own one cell (4 + 9 + 16) and sum its samples sequentially (fixed order = oracle's);
-// then the 486 comparisons are spread over the 64 lanes.
+// bit b (0..485) of the descriptor compares cells ia > ib of channel c: the oracle's enumeration (grid z, channel, pair a < bb
+// in lexicographic order) unrolled into a table at compile time -- entry = ia | ib << 5 | c << 10, cells numbered 0..28
+struct PairTab { unsigned short v[486]; };
+constexpr PairTab make_pair_tab()
+{
+    PairTab t{};
+    int b = 0;
+    const int ncells[3] = {4, 9, 16}, bases[3] = {0, 4, 13};
+    for (int z = 0; z < 3; ++z)
+        for (int c = 0; c < 3; ++c)
+            for (int a = 0; a < ncells[z]; ++a)
+                for (int bb = a + 1; bb < ncells[z]; ++bb)
+                    t.v[b++] = (unsigned short)((bases[z] + a) | ((bases[z] + bb) << 5) | (c << 10));
+    return t;
+}
+static __device__ const PairTab D_PAIRS = make_pair_tab();
+// The 29 cells (4 + 9 + 16) x 3 channels are 87 sequential sums (fixed order = the oracle's): a lane owns one or two of them
+// (the 100-sample sums of the 2 x 2 grid on lanes 0..11 set the length of the phase); then the 486 comparisons are spread
+// over the 64 lanes.
 __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt, const float *__restrict__ Lx, const float *__restrict__ Ly,
                                                    int h, int w, Keypoint *__restrict__ kps, const int32_t *__restrict__ nkp,
                                                    uint8_t *__restrict__ desc, int8_t *__restrict__ bits, int32_t *__restrict__ pop, int F,
@@ -886,37 +903,27 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
         s_patch[0][kk][l] = T[o]; s_patch[1][kk][l] = rx * co + ry * si; s_patch[2][kk][l] = ry * co - rx * si;
     }
     __syncthreads();
-    if (lane < 29) {
-        int z, ci;
-        if (lane < 4) { z = 0; ci = lane; } else if (lane < 13) { z = 1; ci = lane - 4; } else { z = 2; ci = lane - 13; }
-        const int st = z == 0 ? 10 : (z == 1 ? 7 : 5), nc = z + 2;
-        const int i0 = -10 + (ci / nc) * st, j0 = -10 + (ci % nc) * st;       // i (x) major, j (y) minor
-        float di = 0.0f, dx = 0.0f, dy = 0.0f;
-        int ns = 0;
-        for (int kk = i0; kk < i0 + st; ++kk)
-            for (int l = j0; l < j0 + st; ++l) {
-                di = di + s_patch[0][kk + 10][l + 10];
-                dx = dx + s_patch[1][kk + 10][l + 10];
-                dy = dy + s_patch[2][kk + 10][l + 10];
-                ns++;
-            }
-        s_val[lane][0] = di / (float)ns; s_val[lane][1] = dx / (float)ns; s_val[lane][2] = dy / (float)ns;
+    {
+        // tasks 0..86 = cell * 3 + channel; lanes 39..61 take a second one (64..86) after their first
+        auto run_task = [&](int task) {
+            const int cell = task / 3, ch = task - cell * 3;
+            int z, ci;
+            if (cell < 4) { z = 0; ci = cell; } else if (cell < 13) { z = 1; ci = cell - 4; } else { z = 2; ci = cell - 13; }
+            const int st = z == 0 ? 10 : (z == 1 ? 7 : 5), nc = z + 2;
+            const int i0 = (ci / nc) * st, j0 = (ci % nc) * st;       // i (x) major, j (y) minor; offsets already + 10
+            const float *pp = &s_patch[ch][i0][j0];
+            float acc = 0.0f;
+            for (int kk = 0; kk < st; ++kk, pp += 22)
+                for (int l = 0; l < st; ++l) acc = acc + pp[l];
+            s_val[cell][ch] = acc / (float)(st * st);
+        };
+        run_task(lane);
+        if (lane >= 39 && lane < 62) run_task(lane + 25);
     }
     __syncthreads();
-    // bit b (0..485): (z, channel, pair); enumerate in the oracle's order
     for (int b = lane; b < 486; b += 64) {
-        int z, rem, ncell, base;
-        if (b < 18) { z = 0; rem = b; ncell = 4; base = 0; }
-        else if (b < 126) { z = 1; rem = b - 18; ncell = 9; base = 4; }
-        else { z = 2; rem = b - 126; ncell = 16; base = 13; }
-        (void)z;
-        const int npairs = ncell * (ncell - 1) / 2;
-        const int c = rem / npairs;
-        int p = rem - c * npairs;
-        int a = 0;
-        while (p >= ncell - 1 - a) { p -= ncell - 1 - a; a++; }
-        const int bb = a + 1 + p;
-        const int bit = s_val[base + a][c] > s_val[base + bb][c] ? 1 : 0;
+        const uint32_t e = D_PAIRS.v[b];
+        const int bit = s_val[e & 31u][e >> 10] > s_val[(e >> 5) & 31u][e >> 10] ? 1 : 0;
         bq[b] = (int8_t)bit;
         if (bit) atomicOr(&s_words[b >> 5], 1u << (b & 31));
     }
