@@ -444,7 +444,7 @@ __device__ __forceinline__ float deriv_at(const float *I, int h, int w, int y, i
 
 // also writes the Perona-Malik conductivity of the same smoothed plane when `flow` is given (k_ov_flow's arithmetic: the
 // two kernels read the same plane, one launch and one read of it instead of two)
-__global__ __launch_bounds__(256) void k_ov_deriv1(const float *__restrict__ Lsm, float *__restrict__ Lx, float *__restrict__ Ly, int h, int w, int s,
+__global__ __launch_bounds__(256) void k_ov_deriv1(const float *__restrict__ Lsm, float2 *__restrict__ Lxy, int h, int w, int s,
                                                   const float *__restrict__ kc, float *__restrict__ flow)
 {
     const int f = blockIdx.z;
@@ -456,13 +456,12 @@ __global__ __launch_bounds__(256) void k_ov_deriv1(const float *__restrict__ Lsm
     const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * 4;
     const bool inside = bx0 - s >= 0 && bx0 + 63 + s < w && by0 - s >= 0 && by0 + 3 + s < h;
     float gx, gy;
+    // (Lx, Ly) as ONE float2 plane: k_ov_ldet and k_ov_describe want both at the same positions -- one gather instead of two
     if (inside) {
-        Lx[o] = deriv_at<true>(I, h, w, y, x, s, true);
-        Ly[o] = deriv_at<true>(I, h, w, y, x, s, false);
+        Lxy[o] = make_float2(deriv_at<true>(I, h, w, y, x, s, true), deriv_at<true>(I, h, w, y, x, s, false));
         if (flow) scharr_at<true>(I, h, w, y, x, gx, gy);
     } else {
-        Lx[o] = deriv_at(I, h, w, y, x, s, true);
-        Ly[o] = deriv_at(I, h, w, y, x, s, false);
+        Lxy[o] = make_float2(deriv_at(I, h, w, y, x, s, true), deriv_at(I, h, w, y, x, s, false));
         if (flow) scharr_at(I, h, w, y, x, gx, gy);
     }
     if (flow) {
@@ -472,24 +471,37 @@ __global__ __launch_bounds__(256) void k_ov_deriv1(const float *__restrict__ Lsm
     }
 }
 
-__global__ __launch_bounds__(256) void k_ov_ldet(const float *__restrict__ Lx, const float *__restrict__ Ly, float *__restrict__ Ldet, int h, int w, int s)
+// second derivatives of one pixel from the (Lx, Ly) plane: Lxx = d/dx of Lx, Lyy = d/dy of Ly, Lxy = d/dy of Lx -- deriv_at's
+// operations on eight float2 taps (the four corner taps serve all three, the two d/dy centre taps serve Lyy and Lxy)
+template <bool INSIDE>
+__device__ __forceinline__ void second_derivs(const float2 *P, int h, int w, int y, int x, int s, float &lxx, float &lyy, float &lxy)
+{
+    const float wgt = 10.0f / 3.0f;
+    const float norm = 1.0f / (2.0f * (float)s * (wgt + 2.0f));
+    const float wn = wgt * norm;
+    const int ym = INSIDE ? y - s : reflect101(y - s, h), yp = INSIDE ? y + s : reflect101(y + s, h);
+    const int xm = INSIDE ? x - s : reflect101(x - s, w), xp = INSIDE ? x + s : reflect101(x + s, w);
+    const float2 mm = P[(size_t)ym * w + xm], m0 = P[(size_t)ym * w + x], mp = P[(size_t)ym * w + xp];
+    const float2 zm = P[(size_t)y * w + xm], zp = P[(size_t)y * w + xp];
+    const float2 pm = P[(size_t)yp * w + xm], p0 = P[(size_t)yp * w + x], pp = P[(size_t)yp * w + xp];
+    float t0 = norm * (mp.x - mm.x), t1 = wn * (zp.x - zm.x), t2 = norm * (pp.x - pm.x);
+    lxx = (t0 + t1) + t2;
+    t0 = norm * (pm.y - mm.y); t1 = wn * (p0.y - m0.y); t2 = norm * (pp.y - mp.y);
+    lyy = (t0 + t1) + t2;
+    t0 = norm * (pm.x - mm.x); t1 = wn * (p0.x - m0.x); t2 = norm * (pp.x - mp.x);
+    lxy = (t0 + t1) + t2;
+}
+__global__ __launch_bounds__(256) void k_ov_ldet(const float2 *__restrict__ Lxy, float *__restrict__ Ldet, int h, int w, int s)
 {
     const int f = blockIdx.z;
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
-    const float *X = Lx + (size_t)f * h * w, *Y = Ly + (size_t)f * h * w;
+    const float2 *P = Lxy + (size_t)f * h * w;
     const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * 4;
     const bool inside = bx0 - s >= 0 && bx0 + 63 + s < w && by0 - s >= 0 && by0 + 3 + s < h;     // block-uniform
     float lxx, lyy, lxy;
-    if (inside) {
-        lxx = deriv_at<true>(X, h, w, y, x, s, true);
-        lyy = deriv_at<true>(Y, h, w, y, x, s, false);
-        lxy = deriv_at<true>(X, h, w, y, x, s, false);
-    } else {
-        lxx = deriv_at(X, h, w, y, x, s, true);
-        lyy = deriv_at(Y, h, w, y, x, s, false);
-        lxy = deriv_at(X, h, w, y, x, s, false);
-    }
+    if (inside) second_derivs<true>(P, h, w, y, x, s, lxx, lyy, lxy);
+    else second_derivs<false>(P, h, w, y, x, s, lxx, lyy, lxy);
     const float ss = (float)(s * s), s4 = ss * ss;
     Ldet[((size_t)f * h + y) * w + x] = (lxx * lyy - lxy * lxy) * s4;
 }
@@ -817,7 +829,7 @@ static __device__ const PairTab D_PAIRS = make_pair_tab();
 // The 29 cells (4 + 9 + 16) x 3 channels are 87 sequential sums (fixed order = the oracle's): a lane owns one or two of them
 // (the 100-sample sums of the 2 x 2 grid on lanes 0..11 set the length of the phase); then the 486 comparisons are spread
 // over the 64 lanes.
-__global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt, const float *__restrict__ Lx, const float *__restrict__ Ly,
+__global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt, const float2 *__restrict__ Lxy,
                                                    int h, int w, Keypoint *__restrict__ kps, const int32_t *__restrict__ nkp,
                                                    uint8_t *__restrict__ desc, int8_t *__restrict__ bits, int32_t *__restrict__ pop, int F,
                                                    int upright)
@@ -845,8 +857,7 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
     const Keypoint kp = kps[(size_t)f * MAXKP + q];
     const size_t npx = (size_t)h * w;
     const float *T = Lt + ((size_t)kp.level * F + f) * npx;
-    const float *X = Lx + ((size_t)kp.level * F + f) * npx;
-    const float *Y = Ly + ((size_t)kp.level * F + f) * npx;
+    const float2 *XY = Lxy + ((size_t)kp.level * F + f) * npx;
     const float sc = (float)D_SSIZE[kp.level];
     if (lane < 16) s_words[lane] = 0;
     float co = 1.0f, si = 0.0f;
@@ -857,7 +868,8 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
             const int y1 = min(max((int)floorf(kp.y + (float)j * sc + 0.5f), 0), h - 1);
             const float g = D_GAUSS25[abs(i)][abs(j)];
             const size_t o = (size_t)y1 * w + x1;
-            s_v[t] = make_float2(g * X[o], g * Y[o]);
+            const float2 d2 = XY[o];
+            s_v[t] = make_float2(g * d2.x, g * d2.y);
         }
         if (lane < 3) s_v[109 + lane] = make_float2(0.0f, 0.0f);      // a zero vector is in no sector (c2 < 0 fails)
         __syncthreads();
@@ -899,7 +911,8 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
         const int y1 = min(max((int)floorf(sy + 0.5f), 0), h - 1);
         const int x1 = min(max((int)floorf(sx + 0.5f), 0), w - 1);
         const size_t o = (size_t)y1 * w + x1;
-        const float rx = X[o], ry = Y[o];
+        const float2 d2 = XY[o];
+        const float rx = d2.x, ry = d2.y;
         s_patch[0][kk][l] = T[o]; s_patch[1][kk][l] = rx * co + ry * si; s_patch[2][kk][l] = ry * co - rx * si;
     }
     __syncthreads();
@@ -1648,7 +1661,8 @@ dim3 grid2d(int w, int h, int z) { return dim3(uwip_cdiv(w, 64), uwip_cdiv(h, 4)
 
 struct OvWork {
     uint8_t *gray;
-    float *L0, *Lsm, *flow, *ping, *Lt, *Lx, *Ly, *Ldet, *cand, *kc;
+    float *L0, *Lsm, *flow, *ping, *Lt, *Ldet, *cand, *kc;
+    float2 *Lxy;       // (Lx, Ly) interleaved, [NLEV][F][h][w]
     uint32_t *hmax, *khist, *selhist, *sel, *counts;
 };
 
@@ -1662,8 +1676,7 @@ int alloc_work(uwip_ctx *ctx, int F, int h, int w, OvWork *W)
     W->flow = (float *)uwip_ws(ctx, "ov.flow", n * F * 4);
     W->ping = (float *)uwip_ws(ctx, "ov.ping", n * F * 4);
     W->Lt = (float *)uwip_ws(ctx, "ov.Lt", n * F * 4 * NLEV);
-    W->Lx = (float *)uwip_ws(ctx, "ov.Lx", n * F * 4 * NLEV);
-    W->Ly = (float *)uwip_ws(ctx, "ov.Ly", n * F * 4 * NLEV);
+    W->Lxy = (float2 *)uwip_ws(ctx, "ov.Lxy", n * F * 8 * NLEV);
     W->Ldet = (float *)uwip_ws(ctx, "ov.Ldet", n * F * 4 * NLEV);
     W->cand = (float *)uwip_ws(ctx, "ov.cand", n * F * 4 * NLEV);
     W->kc = (float *)uwip_ws(ctx, "ov.kc", sizeof(float) * F);
@@ -1672,7 +1685,7 @@ int alloc_work(uwip_ctx *ctx, int F, int h, int w, OvWork *W)
     W->selhist = (uint32_t *)uwip_ws(ctx, "ov.selhist", sizeof(uint32_t) * 65536 * F);
     W->sel = (uint32_t *)uwip_ws(ctx, "ov.sel", sizeof(uint32_t) * 4 * F);
     W->counts = (uint32_t *)uwip_ws(ctx, "ov.counts", sizeof(uint32_t) * nchunks * F);
-    if (!W->gray || !W->L0 || !W->Lsm || !W->flow || !W->ping || !W->Lt || !W->Lx || !W->Ly || !W->Ldet || !W->cand ||
+    if (!W->gray || !W->L0 || !W->Lsm || !W->flow || !W->ping || !W->Lt || !W->Lxy || !W->Ldet || !W->cand ||
         !W->kc || !W->hmax || !W->khist || !W->selhist || !W->sel || !W->counts)
         return UWIP_ERR_NOMEM;
     return UWIP_OK;
@@ -1706,8 +1719,8 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
                 k_ov_kc_final<<<uwip_cdiv(F, 64), 64, 0, ctx->stream>>>(W.hmax, W.khist, W.kc, F);
             }
             const int s = H_SSIZE[lv];
-            k_ov_deriv1<<<g, 256, 0, ctx->stream>>>(W.Lsm, W.Lx + lv * lvl, W.Ly + lv * lvl, h, w, s, W.kc, lv + 1 < NLEV ? W.flow : nullptr);
-            k_ov_ldet<<<g, 256, 0, ctx->stream>>>(W.Lx + lv * lvl, W.Ly + lv * lvl, W.Ldet + lv * lvl, h, w, s);
+            k_ov_deriv1<<<g, 256, 0, ctx->stream>>>(W.Lsm, W.Lxy + lv * lvl, h, w, s, W.kc, lv + 1 < NLEV ? W.flow : nullptr);
+            k_ov_ldet<<<g, 256, 0, ctx->stream>>>(W.Lxy + lv * lvl, W.Ldet + lv * lvl, h, w, s);
             if (lv + 1 < NLEV) {
                 const float e0 = 0.5f * H_SIGMA[lv] * H_SIGMA[lv], e1 = 0.5f * H_SIGMA[lv + 1] * H_SIGMA[lv + 1];
                 float taus[32];
@@ -1755,7 +1768,7 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
     }
     {
         uwip_kscope ks(ctx, "k_ov_describe");
-        k_ov_describe<<<8u * (((unsigned)MAXKP * F + 7u) / 8u), 64, 0, ctx->stream>>>(W.Lt, W.Lx, W.Ly, h, w, kps, nkp,
+        k_ov_describe<<<8u * (((unsigned)MAXKP * F + 7u) / 8u), 64, 0, ctx->stream>>>(W.Lt, W.Lxy, h, w, kps, nkp,
                                                              ft->d_desc + (size_t)first_slot * MAXKP * DESC_BYTES,
                                                              ft->d_bits + (size_t)first_slot * MAXKP * DESC_K,
                                                              ft->d_pop + (size_t)first_slot * MAXKP, F, upright);
@@ -1937,14 +1950,20 @@ UWIP_API int uwip_overlap_debug_level(uwip_ctx *ctx, int frame, int level, int r
         auto it = ctx->ws.find(name);
         return it == ctx->ws.end() ? nullptr : (float *)it->second.ptr;
     };
-    float *Lt = get("ov.Lt"), *Lx = get("ov.Lx"), *Ly = get("ov.Ly"), *Ld = get("ov.Ldet"), *kc = get("ov.kc");
-    UWIP_REQUIRE(ctx, Lt && Lx && Ly && Ld && kc, "no detect call yet");
+    float *Lt = get("ov.Lt"), *Lxy = get("ov.Lxy"), *Ld = get("ov.Ldet"), *kc = get("ov.kc");
+    UWIP_REQUIRE(ctx, Lt && Lxy && Ld && kc, "no detect call yet");
     UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
     UWIP_REQUIRE(ctx, frame < ctx->ov_last_frames, "frame beyond the last detect batch");
     const size_t off = ((size_t)level * ctx->ov_last_frames + frame) * n;
     if (h_Lt) UWIP_HIP(ctx, hipMemcpy(h_Lt, Lt + off, n * 4, hipMemcpyDeviceToHost));
-    if (h_Lx) UWIP_HIP(ctx, hipMemcpy(h_Lx, Lx + off, n * 4, hipMemcpyDeviceToHost));
-    if (h_Ly) UWIP_HIP(ctx, hipMemcpy(h_Ly, Ly + off, n * 4, hipMemcpyDeviceToHost));
+    if (h_Lx || h_Ly) {        // the derivative pair is one interleaved plane on the device
+        std::vector<float> xy(2 * n);
+        UWIP_HIP(ctx, hipMemcpy(xy.data(), Lxy + 2 * off, n * 8, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; ++i) {
+            if (h_Lx) h_Lx[i] = xy[2 * i];
+            if (h_Ly) h_Ly[i] = xy[2 * i + 1];
+        }
+    }
     if (h_Ldet) UWIP_HIP(ctx, hipMemcpy(h_Ldet, Ld + off, n * 4, hipMemcpyDeviceToHost));
     if (h_kcontrast) UWIP_HIP(ctx, hipMemcpy(h_kcontrast, kc + frame, 4, hipMemcpyDeviceToHost));
     return UWIP_OK;
