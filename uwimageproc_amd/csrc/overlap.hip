@@ -208,27 +208,47 @@ __device__ __forceinline__ void scharr_at(const float *I, int h, int w, int y, i
 
 // ---- contrast factor: 70th percentile of the gradient-magnitude histogram ------------------
 // PASS 0: per-frame max (float bits as uint, values >= 0).  PASS 1: 300-bin histogram.
+constexpr int KC_ROWS = 8;      // groups of four rows per block of k_ov_kc
 template <int PASS>
 __global__ __launch_bounds__(256) void k_ov_kc(const float *__restrict__ Lsm, int h, int w, uint32_t *__restrict__ hmax_bits,
                                               uint32_t *__restrict__ hist /*[F][304]*/)
 {
-    __shared__ uint32_t s_hist[304];
+    // gradient magnitudes of a smooth frame crowd into a few low bins: KC_REP copies of the histogram keyed by the lane,
+    // 304 + 1 words apart (equal bins of neighbouring copies in different banks), so that one atomic instruction rarely
+    // sends many lanes to one word
+    constexpr int KC_REP = 8, KC_STRIDE = 305;
+    __shared__ uint32_t s_hist[PASS == 1 ? KC_REP * KC_STRIDE : 1];
     const int f = blockIdx.z;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const float *I = Lsm + (size_t)f * h * w;
     if (PASS == 1) {
-        for (int i = threadIdx.x; i < 304; i += 256) s_hist[i] = 0;
+        for (int i = threadIdx.x; i < KC_REP * KC_STRIDE; i += 256) s_hist[i] = 0;
         __syncthreads();
     }
-    const bool in = x >= 1 && x < w - 1 && y >= 1 && y < h - 1;
-    float m = 0.0f;
-    if (in) {
-        float gx, gy;
-        scharr_at<true>(I, h, w, y, x, gx, gy);      // in: x +- 1, y +- 1 are pixels of the image
-        m = sqrtf(gx * gx + gy * gy);
+    const float hmax = PASS == 1 ? __uint_as_float(hmax_bits[f]) : 0.0f;
+    uint32_t bmax = 0;
+    // a block walks KC_ROWS groups of four rows: its 300 global atomics (one partial maximum) are paid once per 64 x 32
+    // pixels -- at one group per block 900 blocks of a frame queued on the same few hundred L2 words
+#pragma unroll 2
+    for (int ry = 0; ry < KC_ROWS; ++ry) {
+        const int y = (blockIdx.y * KC_ROWS + ry) * 4 + (threadIdx.x >> 6);
+        const bool in = x >= 1 && x < w - 1 && y >= 1 && y < h - 1;
+        float m = 0.0f;
+        if (in) {
+            float gx, gy;
+            scharr_at<true>(I, h, w, y, x, gx, gy);      // in: x +- 1, y +- 1 are pixels of the image
+            m = sqrtf(gx * gx + gy * gy);
+        }
+        if (PASS == 0) bmax = max(bmax, __float_as_uint(m));
+        else if (in && m != 0.0f && hmax != 0.0f) {
+            int nbin = (int)floorf(300.0f * (m / hmax));
+            if (nbin >= 300) nbin = 299;
+            atomicAdd(&s_hist[(threadIdx.x & (KC_REP - 1)) * KC_STRIDE + nbin], 1u);
+            // npoints = the sum of the bins (k_ov_kc_final): a counter word of its own would take every lane through one address
+        }
     }
     if (PASS == 0) {
-        uint32_t b = __float_as_uint(m);
+        uint32_t b = bmax;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) b = max(b, (uint32_t)__shfl_xor((int)b, d, 64));
         // one partial per block, reduced by k_ov_kc_max (hundreds of blocks polling one word of a frame serialise
@@ -239,16 +259,13 @@ __global__ __launch_bounds__(256) void k_ov_kc(const float *__restrict__ Lsm, in
         if (threadIdx.x == 0)
             hist[((size_t)f * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3]));
     } else {
-        const float hmax = __uint_as_float(hmax_bits[f]);
-        if (in && m != 0.0f && hmax != 0.0f) {
-            int nbin = (int)floorf(300.0f * (m / hmax));
-            if (nbin >= 300) nbin = 299;
-            atomicAdd(&s_hist[nbin], 1u);      // npoints = the sum of the bins (k_ov_kc_final): a counter word of its own
-                                               // would take every lane of every wave through one LDS address
-        }
         __syncthreads();
-        for (int i = threadIdx.x; i < 300; i += 256)
-            if (s_hist[i]) atomicAdd(&hist[(size_t)f * 304 + i], s_hist[i]);
+        for (int i = threadIdx.x; i < 300; i += 256) {
+            uint32_t c = 0;
+#pragma unroll
+            for (int r = 0; r < KC_REP; ++r) c += s_hist[r * KC_STRIDE + i];
+            if (c) atomicAdd(&hist[(size_t)f * 304 + i], c);
+        }
     }
 }
 
@@ -1709,13 +1726,14 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
             float *Lt = W.Lt + lv * lvl;
             launch_conv2(K1.ks, gc, ctx->stream, (const float *)Lt, W.Lsm, h, w, K1);
             if (lv == 0) {
-                const int nbk = (int)(g.x * g.y);
+                const dim3 gk(g.x, uwip_cdiv(g.y, KC_ROWS), g.z);
+                const int nbk = (int)(gk.x * gk.y);
                 uint32_t *kpart = (uint32_t *)uwip_ws(ctx, "ov.kcpart", sizeof(uint32_t) * nbk * F);
                 if (!kpart) return UWIP_ERR_NOMEM;
-                k_ov_kc<0><<<g, 256, 0, ctx->stream>>>(W.Lsm, h, w, W.hmax, kpart);
+                k_ov_kc<0><<<gk, 256, 0, ctx->stream>>>(W.Lsm, h, w, W.hmax, kpart);
                 k_ov_kc_max<<<F, 256, 0, ctx->stream>>>(kpart, nbk, W.hmax);
                 UWIP_HIP(ctx, hipMemsetAsync(W.khist, 0, sizeof(uint32_t) * 304 * F, ctx->stream));
-                k_ov_kc<1><<<g, 256, 0, ctx->stream>>>(W.Lsm, h, w, W.hmax, W.khist);
+                k_ov_kc<1><<<gk, 256, 0, ctx->stream>>>(W.Lsm, h, w, W.hmax, W.khist);
                 k_ov_kc_final<<<uwip_cdiv(F, 64), 64, 0, ctx->stream>>>(W.hmax, W.khist, W.kc, F);
             }
             const int s = H_SSIZE[lv];
