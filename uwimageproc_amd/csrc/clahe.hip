@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void k_bgr_to_v(const uint8_t *__restrict__ sr
 // exact in fixed point, so the result is (sum of the 3x3 window weighted 1 2 1 / 2 4 2 / 1 2 1) / 16 rounded:
 //   rule 0 (OpenCV 3.4.x, bit-exact 8-bit path: ufixedpoint16 -> uchar adds one half and truncates): round half UP
 //   rule 1 (OpenCV 3.2, float rows/columns + cvRound): round half to EVEN.   parity unpinned (OpenCV-internal).
+constexpr int GS3_ROWS = 8;      // rows per block row of the aligned path
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_gauss3_u8(const uint8_t *__restrict__ src, size_t sstep, size_t sfs,
                                                    uint8_t *__restrict__ dst, size_t dstep, size_t dfs, int rows, int cols, int rule)
@@ -139,27 +140,35 @@ __global__ __launch_bounds__(256) void k_gauss3_u8(const uint8_t *__restrict__ s
         return (uint32_t)q;
     };
     if (VEC) {
-        // four pixels per thread: the vertical 1 2 1 sums of six columns (x-1 .. x+4) from three dwords per row, as
-        // 16-bit lanes (<= 4 * 255), then the horizontal 1 2 1
+        // four pixels per thread and GS3_ROWS rows per block row: the horizontal 1 2 1 sums of a row (three dwords: the
+        // thread's own and its two neighbours') are formed once and serve the three output rows they touch -- the window
+        // sum is an exact integer, so horizontal-then-vertical equals vertical-then-horizontal
         const int n4 = cols >> 2;
+        const int y0 = blockIdx.y * GS3_ROWS, y1 = min(y0 + GS3_ROWS, rows);
+        const uint8_t *base = src + (size_t)f * sfs;
         for (int g = blockIdx.x * 256 + threadIdx.x; g < n4; g += gridDim.x * 256) {
             const int gl = g == 0 ? 0 : g - 1, gr = g == n4 - 1 ? g : g + 1;
-            uint32_t v[6];
-            {
-                const uint32_t *p0 = reinterpret_cast<const uint32_t *>(r0), *p1 = reinterpret_cast<const uint32_t *>(r1),
-                               *p2 = reinterpret_cast<const uint32_t *>(r2);
-                const uint32_t a0 = p0[g], a1 = p1[g], a2 = p2[g], l0 = p0[gl], l1 = p1[gl], l2 = p2[gl], q0 = p0[gr], q1 = p1[gr], q2 = p2[gr];
-                auto col = [](uint32_t u0, uint32_t u1, uint32_t u2, int k) { return ((u0 >> (8 * k)) & 255u) + 2u * ((u1 >> (8 * k)) & 255u) + ((u2 >> (8 * k)) & 255u); };
+            // h[k] = s[x-1] + 2 s[x] + s[x+1] of the row's pixels x = 4g + k, reflect-101 at the row ends
+            auto hrow = [&](int yy, uint32_t (&hh)[4]) {
+                const uint32_t *p = reinterpret_cast<const uint32_t *>(base + (size_t)yy * sstep);
+                const uint32_t a = p[g], l = p[gl], q = p[gr];
+                const uint32_t c0 = a & 255u, c1 = (a >> 8) & 255u, c2 = (a >> 16) & 255u, c3 = a >> 24;
+                const uint32_t cm = g == 0 ? c1 : l >> 24, cp = g == n4 - 1 ? c2 : q & 255u;
+                hh[0] = cm + 2u * c0 + c1; hh[1] = c0 + 2u * c1 + c2; hh[2] = c1 + 2u * c2 + c3; hh[3] = c2 + 2u * c3 + cp;
+            };
+            auto refl = [&](int yy) { return rows == 1 ? 0 : (yy < 0 ? 1 : (yy >= rows ? rows - 2 : yy)); };
+            uint32_t ha[4], hb[4], hc[4];
+            hrow(refl(y0 - 1), ha);
+            hrow(y0, hb);
+            for (int yy = y0; yy < y1; ++yy) {
+                hrow(refl(yy + 1), hc);
+                uint32_t o = 0;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) v[1 + k] = col(a0, a1, a2, k);
-                // reflect-101 at the row ends: column -1 mirrors column 1, column W mirrors column W-2
-                v[0] = g == 0 ? v[2] : col(l0, l1, l2, 3);
-                v[5] = g == n4 - 1 ? v[3] : col(q0, q1, q2, 0);
+                for (int k = 0; k < 4; ++k) o |= finish((int)(ha[k] + 2u * hb[k] + hc[k])) << (8 * k);
+                reinterpret_cast<uint32_t *>(dst + (size_t)f * dfs + (size_t)yy * dstep)[g] = o;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { ha[k] = hb[k]; hb[k] = hc[k]; }
             }
-            uint32_t o = 0;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o |= finish((int)(v[k] + 2u * v[k + 1] + v[k + 2])) << (8 * k);
-            reinterpret_cast<uint32_t *>(d)[g] = o;
         }
         return;
     }
@@ -1002,7 +1011,7 @@ UWIP_API int uwip_GaussianBlur3(uwip_ctx *ctx, const uwip_batch_u8 *src, const u
     UWIP_REQUIRE(ctx, src->frames <= 65535 && src->rows <= 65535, "batch too large for one launch");
     uwip_kscope ks(ctx, "k_gauss3_u8");
     const bool vec = src->cols >= 8 && src->cols % 4 == 0 && aligned_for(src, 4) && aligned_for(dst, 4);
-    const dim3 grid(std::min(uwip_cdiv(vec ? src->cols / 4 : src->cols, 256), 64u), (unsigned)src->rows, (unsigned)src->frames);
+    const dim3 grid(std::min(uwip_cdiv(vec ? src->cols / 4 : src->cols, 256), 64u), vec ? uwip_cdiv(src->rows, GS3_ROWS) : (unsigned)src->rows, (unsigned)src->frames);
     if (vec)
         k_gauss3_u8<true><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, (uint8_t *)dst->data, dst->step,
                                                         dst->frame_stride, src->rows, src->cols, rounding_rule);

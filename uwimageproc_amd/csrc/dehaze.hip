@@ -229,6 +229,22 @@ __global__ __launch_bounds__(256) void k_bglight_partial(const uint8_t *__restri
     int i0 = 0x7fffffff, i1 = 0x7fffffff;
     __shared__ double s_T[256];
     fill_table256(s_T, [&](int v) { return normv(v, mn, mxv); });
+    if ((n & 3) == 0 && (((uintptr_t)mx) & 3) == 0) {
+        // four pixels per thread and load (the planes are dense: n bytes each), visited in index order
+        const uint32_t *qB = reinterpret_cast<const uint32_t *>(pB), *qG = reinterpret_cast<const uint32_t *>(pG),
+                       *qR = reinterpret_cast<const uint32_t *>(pR);
+        for (size_t g = (size_t)blockIdx.x * 256 + threadIdx.x; g < n / 4; g += (size_t)gridDim.x * 256) {
+            const uint32_t wb = qB[g], wg = qG[g], wr = qR[g];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const double r = s_T[(wr >> (8 * k)) & 255u];
+                const double d0 = r - s_T[(wb >> (8 * k)) & 255u];
+                const double d1 = r - s_T[(wg >> (8 * k)) & 255u];
+                if (d0 < best0) { best0 = d0; i0 = (int)(4 * g) + k; }     // indices increase per thread: keeps the first
+                if (d1 < best1) { best1 = d1; i1 = (int)(4 * g) + k; }
+            }
+        }
+    } else
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const double r = s_T[pR[i]];
         const double d0 = r - s_T[pB[i]];
