@@ -344,6 +344,19 @@ __global__ __launch_bounds__(256) void k_clahe_tilehist_merge(const uint32_t *__
     hists[((size_t)f * tiles + t) * 256 + v] = c[c00 * 256 + v] + c[(c00 + 1) * 256 + v] + c[(c00 + gx2) * 256 + v] + c[(c00 + gx2 + 1) * 256 + v];
 }
 
+// residual -> stepr | magic << 9 (k_clahe_lut)
+struct SteprTab { uint32_t v[256]; };
+constexpr SteprTab make_stepr_tab()
+{
+    SteprTab t{};
+    for (int r = 0; r < 256; ++r) {
+        const uint32_t stepr = r ? (256u / (uint32_t)r > 1u ? 256u / (uint32_t)r : 1u) : 1u;
+        t.v[r] = stepr | ((65536u / stepr + 1u) << 9);
+    }
+    return t;
+}
+static __device__ const SteprTab D_STEPR = make_stepr_tab();
+
 // ---- C1b: clip, redistribute, cumulative LUT --------------------------------
 // One wave per (tile, frame); lane l owns bins 4l..4l+3 and the wave walks all clip limits with shuffle-only
 // reductions and scans (no barriers).  Arithmetic is cv::CLAHE's: integer clip / redistribute, then
@@ -369,8 +382,11 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
     auto lut_word = [&](const int h[4]) {
         const int p0 = h[0], p1 = p0 + h[1], p2 = p1 + h[2], p3 = p2 + h[3];
         const int off = (int)wave_incl_scan_u32((uint32_t)p3) - p3;
-        return sat_u8_rne((float)(off + p0) * lutScale) | (sat_u8_rne((float)(off + p1) * lutScale) << 8) |
-               (sat_u8_rne((float)(off + p2) * lutScale) << 16) | (sat_u8_rne((float)(off + p3) * lutScale) << 24);
+        // sum * lutScale lies in [0, 255.0001]: v_cvt_pk_u8_f32 (round to nearest even, clamp, byte insert) is sat_u8_rne there
+        uint32_t wv = __builtin_amdgcn_cvt_pk_u8_f32((float)(off + p0) * lutScale, 0, 0u);
+        wv = __builtin_amdgcn_cvt_pk_u8_f32((float)(off + p1) * lutScale, 1, wv);
+        wv = __builtin_amdgcn_cvt_pk_u8_f32((float)(off + p2) * lutScale, 2, wv);
+        return __builtin_amdgcn_cvt_pk_u8_f32((float)(off + p3) * lutScale, 3, wv);
     };
     const uint32_t w_unclipped = lut_word(h0);
     for (int c = 0; c < ncl; ++c) {
@@ -382,13 +398,15 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
 #pragma unroll
             for (int k = 0; k < 4; ++k) { excess += max(h[k] - clip, 0); h[k] = min(h[k], clip); }
             excess = (int)wave_sum_u32((uint32_t)excess);
-            const int batch = excess / 256;
-            const int residual = excess - batch * 256;
-            const int stepr = residual ? max(256 / residual, 1) : 1;
-            // v / stepr for v < 256, stepr <= 256 without a per-lane integer division (quarter-rate multiplies and a
-            // reciprocal sequence, eight times per clip limit): q = (v * m) >> 16 with m = floor(2^16 / stepr) + 1 is exact
-            // here, since v * (m * stepr - 2^16) <= 255 * 256 < 2^16.  stepr and m are wave-uniform.
-            const uint32_t magic = 65536u / (uint32_t)stepr + 1u;
+            const int batch = excess >> 8;
+            const int residual = excess & 255;
+            // stepr = max(256 / residual, 1) and, for v / stepr with v < 256 without a per-lane integer division, the
+            // multiplier m = floor(2^16 / stepr) + 1 (q = (v * m) >> 16 is exact here: v * (m * stepr - 2^16) <= 255 * 256 <
+            // 2^16) -- both from a 256-entry table indexed by the wave-uniform residual instead of two division sequences
+            // per clip limit
+            const uint32_t sm = D_STEPR.v[__builtin_amdgcn_readfirstlane(residual)];
+            const int stepr = (int)(sm & 511u);
+            const uint32_t magic = sm >> 9;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int v = lane * 4 + k;
