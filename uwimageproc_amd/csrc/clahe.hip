@@ -1391,9 +1391,10 @@ __device__ __forceinline__ void hsv_replace_px(int b, int g, int r, int vnew, co
             default: ob = t2; og = t1; orr = t0; break;
         }
     }
-    ob8 = (uint32_t)sat_u8_rne(ob * 255.f);
-    og8 = (uint32_t)sat_u8_rne(og * 255.f);
-    or8 = (uint32_t)sat_u8_rne(orr * 255.f);
+    // the three values lie in [0, 1]: v_cvt_pk_u8_f32 (round to nearest even + clamp) is saturate_cast<uchar> there
+    ob8 = __builtin_amdgcn_cvt_pk_u8_f32(ob * 255.f, 0, 0u);
+    og8 = __builtin_amdgcn_cvt_pk_u8_f32(og * 255.f, 0, 0u);
+    or8 = __builtin_amdgcn_cvt_pk_u8_f32(orr * 255.f, 0, 0u);
 }
 
 constexpr int HSV_ROWS_PER_BLOCK = 8;
