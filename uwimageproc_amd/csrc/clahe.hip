@@ -603,9 +603,21 @@ __device__ __forceinline__ void sweep_run(const uint32_t *pack_v, uint32_t *my_h
     uint32_t pk[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) pk[i] = pack_v[(K0 + i) * 256];
+    // Limits 2j and 2j + 1 share a counter word (low / high half).  Where a pixel's two outputs agree -- neighbouring limits
+    // often blend the same four LUT entries -- ONE atomic adds to both halves, and the second one runs only for the lanes that
+    // differ (fewer active lanes = fewer same-bank collisions in the LDS pipe, the kernel's other limit).
+    uint32_t o[N];
 #pragma unroll
-    for (int i = 0; i < N; ++i)
-        atomicAdd(&my_hist[((K0 + i) >> 1) * 256 + sweep_eval(pk[i], xa1, xa, ya1, ya)], ((K0 + i) & 1) ? 65536u : 1u);
+    for (int i = 0; i < N; ++i) o[i] = sweep_eval(pk[i], xa1, xa, ya1, ya);
+    constexpr int FIRST = K0 & 1;            // an odd first limit is the high half of a word on its own
+    if constexpr (FIRST) atomicAdd(&my_hist[(K0 >> 1) * 256 + o[0]], 65536u);
+#pragma unroll
+    for (int i = FIRST; i + 1 < N; i += 2) {
+        const bool same = o[i] == o[i + 1];
+        atomicAdd(&my_hist[((K0 + i) >> 1) * 256 + o[i]], same ? 0x10001u : 1u);
+        if (!same) atomicAdd(&my_hist[((K0 + i) >> 1) * 256 + o[i + 1]], 65536u);
+    }
+    if constexpr (((N - FIRST) & 1) != 0) atomicAdd(&my_hist[((K0 + N - 1) >> 1) * 256 + o[N - 1]], 1u);
 }
 
 __global__ __launch_bounds__(SWEEP_THREADS) void k_clahe_sweep(const uint8_t *__restrict__ src, size_t step,
