@@ -280,14 +280,21 @@ __global__ void k_bglight_final(const double *__restrict__ pval, const int *__re
                                 int *__restrict__ si, double *__restrict__ sc)
 {
     const int f = blockIdx.x;
-    if (threadIdx.x != 0) return;
     double b0 = 1e300, b1 = 1e300;
     int i0 = 0x7fffffff, i1 = 0x7fffffff;
-    for (int b = 0; b < nb; ++b) {
+    for (int b = (int)threadIdx.x; b < nb; b += 64) {        // launched with one wave; (value, index) order = first-index ties
         const size_t o = ((size_t)f * nb + b) * 2;
         if (pval[o] < b0 || (pval[o] == b0 && pidx[o] < i0)) { b0 = pval[o]; i0 = pidx[o]; }
         if (pval[o + 1] < b1 || (pval[o + 1] == b1 && pidx[o + 1] < i1)) { b1 = pval[o + 1]; i1 = pidx[o + 1]; }
     }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        const double v0 = __shfl_xor(b0, sft, 64), v1 = __shfl_xor(b1, sft, 64);
+        const int j0 = __shfl_xor(i0, sft, 64), j1 = __shfl_xor(i1, sft, 64);
+        if (v0 < b0 || (v0 == b0 && j0 < i0)) { b0 = v0; i0 = j0; }
+        if (v1 < b1 || (v1 == b1 && j1 < i1)) { b1 = v1; i1 = j1; }
+    }
+    if (threadIdx.x != 0) return;
     int *s = si + (size_t)f * SI_COUNT;
     double *d = sc + (size_t)f * SC_COUNT;
     // A constant frame (max == min) normalises to 0/0 = NaN everywhere: no difference ever compares below the running
@@ -386,13 +393,20 @@ __global__ void k_recover_final2(const double *__restrict__ jpart, int nb, const
                                  const int *__restrict__ si, double *__restrict__ sc, double npix)
 {
     const int f = blockIdx.x;
-    if (threadIdx.x != 0) return;
+    // the wave (launched with 64 threads) shares the nb partials of the frame's two planes: a single thread walking them is a
+    // chain of dependent loads (a few hundred partials at 4K)
     double a = 1e300, b = -1e300, c = 1e300, d = -1e300, s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < nb; ++k) {
+    for (int k = (int)threadIdx.x; k < nb; k += 64) {
         const double *p0 = jpart + ((size_t)(2 * f) * nb + k) * 3, *p1 = jpart + ((size_t)(2 * f + 1) * nb + k) * 3;
         a = fmin(a, p0[0]); b = fmax(b, p0[1]); s0 += p0[2];
         c = fmin(c, p1[0]); d = fmax(d, p1[1]); s1 += p1[2];
     }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        a = fmin(a, __shfl_xor(a, sft, 64)); b = fmax(b, __shfl_xor(b, sft, 64)); s0 += __shfl_xor(s0, sft, 64);
+        c = fmin(c, __shfl_xor(c, sft, 64)); d = fmax(d, __shfl_xor(d, sft, 64)); s1 += __shfl_xor(s1, sft, 64);
+    }
+    if (threadIdx.x != 0) return;
     const int *ii = si + (size_t)f * SI_COUNT;
     const int mn = ii[SI_MN], mx = ii[SI_MX];
     const double sumr = (double)((long long)redsum[f] - (long long)npix * mn);
@@ -647,12 +661,16 @@ __global__ __launch_bounds__(256) void k_exp_out(const uint8_t *__restrict__ img
 __global__ void k_exp_out_final(const double *__restrict__ part, int nb, double *__restrict__ sc)
 {
     const int f = blockIdx.x;
-    if (threadIdx.x != 0) return;
     double a = 1e300, b = -1e300, c = 0.0;
-    for (int k = 0; k < nb; ++k) {
+    for (int k = (int)threadIdx.x; k < nb; k += 64) {        // launched with one wave
         const double *p = part + ((size_t)f * nb + k) * 3;
         a = fmin(a, p[0]); b = fmax(b, p[1]); c = fmax(c, p[2]);
     }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        a = fmin(a, __shfl_xor(a, sft, 64)); b = fmax(b, __shfl_xor(b, sft, 64)); c = fmax(c, __shfl_xor(c, sft, 64));
+    }
+    if (threadIdx.x != 0) return;
     if (c != 0.0) a = b = __longlong_as_double(0x7ff8000000000000ll);
     sc[(size_t)f * SC_COUNT + SC_OMN] = a;
     sc[(size_t)f * SC_COUNT + SC_OMX] = b;
