@@ -1,3 +1,4 @@
+# FETCH_SIZE of k_gf_ws_final with one and four waves per strip; GPU box:  bash tools/gf_final_nw_pmc.sh
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 for n in 1 4; do
   export UWIP_GF_FINAL_NW=$n
