@@ -396,18 +396,21 @@ inline bool decode(const uint8_t *buf, size_t len, int &rows, int &cols, int &ch
     channels = 3;
     pix.resize((size_t)W * H * 3);
     // jdcolor.c build_ycc_rgb_table: SCALEBITS 16
-    static int32_t crr[256], cbb[256], crg[256], cbg[256];
-    static bool init = false;
-    if (!init) {
-        for (int i = 0; i < 256; ++i) {
-            const int32_t x = i - 128;
-            crr[i] = (int32_t)((91881LL * x + 32768) >> 16);           // FIX(1.40200)
-            cbb[i] = (int32_t)((116130LL * x + 32768) >> 16);          // FIX(1.77200)
-            crg[i] = (int32_t)(-46802LL * x);                          // FIX(0.71414)
-            cbg[i] = (int32_t)(-22554LL * x + 32768);                  // FIX(0.34414) + ONE_HALF
+    // built once, thread-safe (C++11 function-local static: `videostrip -g N` decodes from N worker threads)
+    struct YccTables {
+        int32_t crr[256], cbb[256], crg[256], cbg[256];
+        YccTables() {
+            for (int i = 0; i < 256; ++i) {
+                const int32_t x = i - 128;
+                crr[i] = (int32_t)((91881LL * x + 32768) >> 16);           // FIX(1.40200)
+                cbb[i] = (int32_t)((116130LL * x + 32768) >> 16);          // FIX(1.77200)
+                crg[i] = (int32_t)(-46802LL * x);                          // FIX(0.71414)
+                cbg[i] = (int32_t)(-22554LL * x + 32768);                  // FIX(0.34414) + ONE_HALF
+            }
         }
-        init = true;
-    }
+    };
+    static const YccTables tab;
+    const int32_t *crr = tab.crr, *cbb = tab.cbb, *crg = tab.crg, *cbg = tab.cbg;
     auto clamp8 = [](int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
     for (size_t i = 0; i < (size_t)W * H; ++i) {
         const int y = Y[i], cb = Cb[i], cr = Cr[i];

@@ -101,8 +101,10 @@ int uwip_memcpy_d2h_async(uwip_ctx *ctx, void *h_dst, const void *d_src, size_t 
 /* Copy engine for a stream of frame batches (the double-buffered form of
  * GpuMat::upload ... download around the timed region, histretch.cpp:165-216;
  * SURVEY.md section 7 "PCIe feed").  One per device / rank: an upload lane and a
- * download lane, each a host thread with a stream of its own that serves its
- * requests first in, first out.  A request with `after` != NULL starts once
+ * download lane, each a host thread with a stream of its own that serves the
+ * first queued request whose dependency has completed (requests that depend on
+ * the same context are served in their order; one whose stream is still busy
+ * does not hold back the ready requests of other contexts).  A request with `after` != NULL starts once
  * everything queued on that context's stream AT THE TIME OF THE CALL has
  * finished (the lane waits for it on the host, so a copy is only handed to the
  * DMA engine when it can run: no hardware queue ever holds a barrier packet
@@ -111,7 +113,12 @@ int uwip_memcpy_d2h_async(uwip_ctx *ctx, void *h_dst, const void *d_src, size_t 
  * names the request: uwip_copier_wait blocks the calling host thread until
  * that copy has completed (ticket 0: returns at once), after which the host
  * buffer may be reused (upload) or read (download), and the device buffer may
- * be read by kernels queued from then on.  Requests may come from any thread. */
+ * be read by kernels queued from then on.  Requests may come from any thread.
+ * uwip_copier_create leaves the caller's current HIP device as it found it.
+ * Failure is sticky: after the first HIP error in a lane every later submit /
+ * wait / query returns UWIP_ERR_HIP (uwip_copier_last_error says what failed;
+ * queued requests are completed without copying so that no waiter blocks) and
+ * the copier must be destroyed and created anew -- there is no reset. */
 typedef struct uwip_copier uwip_copier;
 int uwip_copier_create(int device, uwip_copier **out);
 int uwip_copier_destroy(uwip_copier *c);                 /* drains both lanes first */
@@ -361,6 +368,16 @@ int uwip_overlap_match(uwip_ctx *ctx, const uwip_features *fq, const uwip_featur
                        const int32_t *h_pair_q, const int32_t *h_pair_t, int npairs, int videoWidth,
                        int videoHeight, uint32_t seed, float *d_ratio, int32_t *d_info, double *d_H,
                        int32_t *d_match_idx, int32_t *d_match_dist);
+/* Same with flags.  By default a homography supported by fewer than 6 RANSAC inliers is reported as none (-2.0): four
+ * matches always fit one exactly, and with the contrast-relative detector threshold two frames of pure sensor noise now
+ * and then produce four chance matches.  This is a DEVIATION from the reference, which takes whatever findHomography
+ * returns for >= 4 good matches (videostrip.cpp:252-272).  UWIP_OVERLAP_MIN4 restores the reference's rule: any
+ * hypothesis with >= 4 inliers (i.e. any solvable sample of four good matches) yields an overlap value. */
+#define UWIP_OVERLAP_MIN4 4u
+int uwip_overlap_match_ex(uwip_ctx *ctx, const uwip_features *fq, const uwip_features *ft,
+                          const int32_t *h_pair_q, const int32_t *h_pair_t, int npairs, int videoWidth,
+                          int videoHeight, uint32_t seed, unsigned flags, float *d_ratio, int32_t *d_info,
+                          double *d_H, int32_t *d_match_idx, int32_t *d_match_dist);
 /* overlapArea(Mat H), videostrip.cpp:291-319, for n row-major 3x3 double homographies. */
 int uwip_overlapArea(uwip_ctx *ctx, const double *d_H, int n, int videoWidth, int videoHeight,
                      float *d_ratio, int32_t *d_count);

@@ -754,8 +754,18 @@ static int refit(const float *ox, const float *oy, const float *sx, const float 
 /* findHomography(obj, scene, RANSAC) stand-in; returns the inlier count of the chosen
  * hypothesis (0 = no model: the reference's "H.empty()").  (w, h) = image size used for
  * the fixed normalisation of the refit. */
+ORC_API int orc_find_homography_ex(const float *ox, const float *oy, const float *sx, const float *sy, int n, int w, int h,
+                                   uint32_t seed, double H[9], int min_inliers);
 ORC_API int orc_find_homography(const float *ox, const float *oy, const float *sx, const float *sy, int n, int w, int h,
                                 uint32_t seed, double H[9])
+{
+    return orc_find_homography_ex(ox, oy, sx, sy, n, w, h, seed, H, OV_MIN_INLIERS);
+}
+
+/* min_inliers: OV_MIN_INLIERS (6) by default; 4 = the reference's rule (any homography findHomography returns for >= 4
+ * good matches is used, videostrip.cpp:252-272) */
+ORC_API int orc_find_homography_ex(const float *ox, const float *oy, const float *sx, const float *sy, int n, int w, int h,
+                                   uint32_t seed, double H[9], int min_inliers)
 {
     if (n < 4) return 0;
     int best = 0, best_it = -1;
@@ -769,7 +779,7 @@ ORC_API int orc_find_homography(const float *ox, const float *oy, const float *s
         for (int i = 0; i < n; ++i) cnt += is_inlier(Hc, ox[i], oy[i], sx[i], sy[i]);
         if (cnt > best) { best = cnt; best_it = it; memcpy(Hb, Hc, sizeof Hb); }
     }
-    if (best < OV_MIN_INLIERS || best_it < 0) return 0;
+    if (best < min_inliers || best_it < 0) return 0;
     uint8_t *inl = (uint8_t *)malloc((size_t)n);
     for (int i = 0; i < n; ++i) inl[i] = (uint8_t)is_inlier(Hb, ox[i], oy[i], sx[i], sy[i]);
     double Hr[9];
@@ -967,7 +977,7 @@ ORC_API float orc_calcOverlap(const uint8_t *key, const uint8_t *obj, int rows, 
     return orc_calcOverlap_ex(key, obj, rows, cols, step, videoWidth, videoHeight, seed, info, Hout, 0);
 }
 
-/* flags: bit 0 = upright descriptors, bit 1 = fixed detector threshold */
+/* flags: bit 0 = upright descriptors, bit 1 = fixed detector threshold, bit 2 = the reference's ">= 4 matches" rule */
 ORC_API float orc_calcOverlap_ex(const uint8_t *key, const uint8_t *obj, int rows, int cols, size_t step, int videoWidth,
                                  int videoHeight, uint32_t seed, int32_t *info, double *Hout, int flags)
 {
@@ -991,7 +1001,7 @@ ORC_API float orc_calcOverlap_ex(const uint8_t *key, const uint8_t *obj, int row
         float *ox = (float *)malloc(4 * ng), *oy = (float *)malloc(4 * ng), *sx = (float *)malloc(4 * ng), *sy = (float *)malloc(4 * ng);
         for (int i = 0; i < ng; ++i) { ox[i] = ko[gq[i]].x; oy[i] = ko[gq[i]].y; sx[i] = kk[gt[i]].x; sy[i] = kk[gt[i]].y; }
         double H[9];
-        ninl = orc_find_homography(ox, oy, sx, sy, ng, ow, oh, seed, H);
+        ninl = orc_find_homography_ex(ox, oy, sx, sy, ng, ow, oh, seed, H, (flags & 4) ? 4 : OV_MIN_INLIERS);
         if (ninl > 0) {
             result = orc_overlapArea(H, videoWidth, videoHeight, &ovc);
             if (Hout) memcpy(Hout, H, sizeof H);

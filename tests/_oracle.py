@@ -62,6 +62,8 @@ class Oracle:
         L.orc_ratio_test.argtypes = [i32p, i32p, C.c_int, C.c_int, i32p, i32p]
         L.orc_find_homography.restype = C.c_int
         L.orc_find_homography.argtypes = [f32p, f32p, f32p, f32p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.POINTER(C.c_double)]
+        L.orc_find_homography_ex.restype = C.c_int
+        L.orc_find_homography_ex.argtypes = L.orc_find_homography.argtypes + [C.c_int]
         L.orc_overlapArea.restype = C.c_float
         L.orc_overlapArea.argtypes = [C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_int32)]
         L.orc_calcOverlap.restype = C.c_float
@@ -172,10 +174,10 @@ class Oracle:
         n = self.lib.orc_ratio_test(np.ascontiguousarray(idx).reshape(-1), np.ascontiguousarray(dist).reshape(-1), nq, nt, gq, gt)
         return gq[:n], gt[:n]
 
-    def find_homography(self, ox, oy, sx, sy, w, h, seed=1):
+    def find_homography(self, ox, oy, sx, sy, w, h, seed=1, min_inliers=6):
         H = (C.c_double * 9)()
         a = [np.ascontiguousarray(v, np.float32) for v in (ox, oy, sx, sy)]
-        n = self.lib.orc_find_homography(a[0], a[1], a[2], a[3], len(a[0]), w, h, seed, H)
+        n = self.lib.orc_find_homography_ex(a[0], a[1], a[2], a[3], len(a[0]), w, h, seed, H, min_inliers)
         return n, np.array(list(H)).reshape(3, 3)
 
     def overlapArea(self, H, vw, vh):
@@ -184,13 +186,14 @@ class Oracle:
         r = self.lib.orc_overlapArea(Hc, vw, vh, C.byref(cnt))
         return float(r), cnt.value
 
-    def calcOverlap(self, key, obj, vw=None, vh=None, seed=1, upright=False, fixed_threshold=False):
+    def calcOverlap(self, key, obj, vw=None, vh=None, seed=1, upright=False, fixed_threshold=False, min4=False):
         key, obj = np.ascontiguousarray(key), np.ascontiguousarray(obj)
         vw = key.shape[1] if vw is None else vw
         vh = key.shape[0] if vh is None else vh
         info = (C.c_int32 * 8)()
         H = (C.c_double * 9)()
-        r = self.lib.orc_calcOverlap_ex(key, obj, key.shape[0], key.shape[1], key.strides[0], vw, vh, seed, info, H, (1 if upright else 0) | (2 if fixed_threshold else 0))
+        r = self.lib.orc_calcOverlap_ex(key, obj, key.shape[0], key.shape[1], key.strides[0], vw, vh, seed, info, H,
+                                        (1 if upright else 0) | (2 if fixed_threshold else 0) | (4 if min4 else 0))
         return float(r), list(info)[:5], np.array(list(H)).reshape(3, 3)
 
     # ---- numpy-friendly wrappers ----

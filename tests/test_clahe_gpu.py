@@ -3,6 +3,8 @@ oracle.  Integer stages and the float32 interpolation are bit-exact; entropy
 is compared within 1e-5 abs (device log2 vs libm)."""
 import numpy as np
 import pytest
+
+import _knee_mirror as knee_mirror   # the scipy mirror of functions.py:49-93 (a checker: lives with the tests)
 import torch
 
 from uwimageproc_amd import aclahe, synth
@@ -178,7 +180,7 @@ def test_aclahe_auto_ex_vs_oracle_1080p(ctx, orc):
         dst, params = aclahe.auto(ctx, t, prefilter=prefilter)
         for f in range(2):
             src = orc.gaussian3(v[f]) if prefilter else v[f]
-            bs, cl = aclahe.select_parameters(orc.sweep(src))
+            bs, cl = knee_mirror.select_parameters(orc.sweep(src))
             assert params[f] == (bs, cl), (prefilter, f, params[f], (bs, cl))
             assert np.array_equal(dst[f].cpu().numpy(), orc.clahe(v[f], float(cl), bs, bs))
 
@@ -242,7 +244,7 @@ def test_aclahe_auto_matches_staged_path(ctx, orc):
     ctx.sync()
     got = out.cpu().numpy()
     for f in range(5):
-        ebs, ecl = aclahe.select_parameters(orc.sweep(frames[f]))          # scipy mirror on the oracle's table
+        ebs, ecl = knee_mirror.select_parameters(orc.sweep(frames[f]))          # scipy mirror on the oracle's table
         assert (bs[f], cl[f]) == (ebs, ecl)
         assert np.array_equal(got[f], orc.clahe(frames[f], float(ecl), ebs, ebs))
 
@@ -273,7 +275,25 @@ def test_aclahe_auto_python_and_cpp_driver_modes(ctx, orc):
         dst, params = aclahe.auto(ctx, t, prefilter=prefilter)
         for f in range(2):
             src = orc.gaussian3(v[f]) if prefilter else v[f]
-            bs, cl = aclahe.select_parameters(orc.sweep(src))
+            bs, cl = knee_mirror.select_parameters(orc.sweep(src))
             assert params[f] == (bs, cl), (prefilter, f, params[f], (bs, cl))
             assert np.array_equal(dst[f].cpu().numpy(), orc.clahe(v[f], float(cl), bs, bs))     # final apply: unfiltered plane
         assert aclahe.ParametrosACLAHE(ctx, t, prefilter=prefilter) == params
+
+
+@pytest.mark.parametrize("value", [200, 201])
+def test_tilehist_16bit_slots_do_not_overflow_on_constant_4k_tiles(ctx, orc, value):
+    """the slot-keyed tile histogram counts in 16-bit halves.  With many frames in the batch the host gives
+    every (tile, frame) a single wave; a constant 1920x1080 tile of a 4K frame then puts > 65536 pixels into one slot
+    unless the part size is bounded (launch_tilehist: TH_BP_PART_MAX).  Even value = low half carries into the odd bin,
+    odd value = high half wraps."""
+    F, H, W = 520, 2160, 3840
+    t = torch.full((F, H, W), value, dtype=torch.uint8, device="cuda")
+    c = aclahe.CLAHE(ctx, 0.0, (2, 2))
+    luts = c.luts(t).cpu().numpy()
+    _, exp = orc.clahe(np.full((H, W), value, np.uint8), 0.0, 2, 2, 0, want_luts=True)
+    for f in (0, 1, F // 2, F - 1):
+        assert np.array_equal(luts[f], exp), f
+    assert (luts == luts[0]).all()
+    del t
+    torch.cuda.empty_cache()

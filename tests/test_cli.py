@@ -6,6 +6,8 @@ import sys
 
 import numpy as np
 import pytest
+
+import _knee_mirror as knee_mirror   # the scipy mirror of functions.py:49-93 (a checker: lives with the tests)
 from PIL import Image
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -127,7 +129,7 @@ def test_aclahe_and_bgdehaze_cli(tmp_path, orc):
     r = subprocess.run([os.path.join(BIN, "aclahe"), a, b], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     v = orc.bgr_to_v(img)
-    bs, cl = aclahe.select_parameters(orc.sweep(v))
+    bs, cl = knee_mirror.select_parameters(orc.sweep(v))
     assert f"Block size: {bs}" in r.stdout and f"Clip limit: {cl}" in r.stdout
     assert np.array_equal(_load_png(b), orc.hsv_replace_v(img, orc.clahe(v, float(cl), bs, bs)))
     rows = [l for l in r.stdout.splitlines() if l.count(" ") >= 50]

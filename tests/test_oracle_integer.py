@@ -6,6 +6,8 @@ numbers are the pin; bit-exactness vs a real OpenCV 3.4.6 remains unconfirmed
 import numpy as np
 import pytest
 
+import _knee_mirror as knee_mirror   # the scipy mirror of functions.py:49-93 (a checker: lives with the tests)
+
 from uwimageproc_amd import synth
 
 
@@ -322,7 +324,7 @@ def test_native_knee_matches_scipy_mirror(orc):
             ys = np.ascontiguousarray(tab[gi][1:50], np.float32)
             k = C.c_int32(0)
             nat.lib().uwip_aclahe_knee(xs.ctypes.data_as(C.POINTER(C.c_float)), ys.ctypes.data_as(C.POINTER(C.c_float)), C.byref(k))
-            assert k.value == aclahe.knee_index(xs, ys)
+            assert k.value == knee_mirror.knee_index(xs, ys)
 
 
 def test_hsv_known_values(orc):

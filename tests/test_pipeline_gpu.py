@@ -7,6 +7,8 @@ import sys
 
 import numpy as np
 import pytest
+
+import _knee_mirror as knee_mirror   # the scipy mirror of functions.py:49-93 (a checker: lives with the tests)
 import torch
 
 from uwimageproc_amd import aclahe, synth
@@ -41,7 +43,7 @@ def test_full_pipe_small_stream(orc):
     for f in range(F):
         st, _ = orc.histretch(dehazed[f], "RGB")
         v = orc.bgr_to_v(st)
-        bs, cl = aclahe.select_parameters(orc.sweep(orc.gaussian3(v)))
+        bs, cl = knee_mirror.select_parameters(orc.sweep(orc.gaussian3(v)))
         assert pipe.params[f] == (bs, cl)
         e = orc.hsv_replace_v(st, orc.clahe(v, float(cl), bs, bs))
         assert np.array_equal(out[f], e), f
@@ -124,7 +126,7 @@ def test_config5_full_pipe_4k(orc):
         st, _ = orc.histretch(dehazed[f], "RGB")
         v = orc.bgr_to_v(st)
         if f == 0:   # the 255-evaluation sweep of the oracle takes a while at this size: one frame
-            assert params[f] == aclahe.select_parameters(orc.sweep(orc.gaussian3(v)))
+            assert params[f] == knee_mirror.select_parameters(orc.sweep(orc.gaussian3(v)))
         bs, cl = params[f]
         e = orc.hsv_replace_v(st, orc.clahe(v, float(cl), bs, bs))
         assert np.array_equal(out[f], e), f

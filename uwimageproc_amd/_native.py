@@ -112,6 +112,8 @@ SIGNATURES = {
     "uwip_overlap_debug_level": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
     "uwip_overlap_match": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
                                      C.c_uint32, _P, _P, _P, _P, _P]),
+    "uwip_overlap_match_ex": (C.c_int, [_P, _P, _P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int,
+                                        C.c_uint32, C.c_uint, _P, _P, _P, _P, _P]),
     "uwip_overlapArea": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "uwip_calcBlur": (C.c_int, [_P, _B, _P]),
 }

@@ -864,12 +864,19 @@ int launch_tilehist(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g,
     // one wave per (tile, row part).  Large aligned tiles take the slot-keyed form: parts of >= TH_BP_MIN pixels, enough of
     // them for ~4096 waves; small or unaligned tiles the replica form: enough parts for >= 16384 waves, at
     // least 8 rows each.
-    const bool bp = (long long)g.tw * g.th >= TH_BP_MIN && (g.tw & 15) == 0 && g.tw * g.gx == g.cols &&
+    // The slot-keyed form counts in 16-bit halves: a slot is shared by the lanes l = s mod 16 of a wave, at most 4 of at
+    // least 33 active ones, so it sees at most 1/8 of its part's pixels -- a part must stay below 2^19 pixels or a constant
+    // (saturated / black) tile carries the even bin's counter into the odd bin's.  TH_BP_PART_MAX keeps a margin for
+    // the rounding of rows_per_part (one more row of < 2^17 columns); wider tiles take the 32-bit replica form.
+    constexpr long long TH_BP_PART_MAX = 3ll << 17;                   // 393 216 pixels
+    const bool bp = (long long)g.tw * g.th >= TH_BP_MIN && (g.tw & 15) == 0 && g.tw * g.gx == g.cols && g.tw < (1 << 17) &&
                     ((reinterpret_cast<uintptr_t>(src->data) | src->step | src->frame_stride) & 15u) == 0;
     int split;
     if (bp) {
         split = (int)((4096 + (size_t)tiles * nf - 1) / ((size_t)tiles * nf));
         split = std::max(1, std::min(split, (int)(((long long)g.tw * g.th) / TH_BP_MIN)));
+        split = std::max(split, (int)(((long long)g.tw * g.th + TH_BP_PART_MAX - 1) / TH_BP_PART_MAX));
+        split = std::min(split, g.th);
     } else {
         split = (int)((16384 + (size_t)tiles * nf - 1) / ((size_t)tiles * nf));
         split = std::max(1, std::min(split, std::max(1, g.th / 8)));

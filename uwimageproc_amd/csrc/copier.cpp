@@ -7,12 +7,17 @@
 // shares with an unrelated compute stream and holds that stream's kernels for the length of the copy (7-30 ms).
 // Here no such packet exists: a lane thread waits for a request's dependency ON THE HOST, hands the copy to the DMA
 // engine when it can run, waits for it on the host, and publishes the ticket; the pipes wait for tickets on the host.
-// Copies of one direction run one at a time at the full link rate (57 GB/s), in request order.
+// Copies of one direction run one at a time at the full link rate (57 GB/s).  A lane serves the FIRST QUEUED request whose
+// dependency has completed (hipEventQuery), so a download whose stream is still busy does not hold back the ready
+// downloads of other pipes; requests that depend on the same stream are still served in their order (an event recorded
+// later on a stream cannot complete before an earlier one).  When nothing is ready the lane sleeps on the head request's
+// event.  Completion is published per ticket.
 #include "uwip_internal.hpp"
 #include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <set>
 #include <thread>
 
 namespace {
@@ -33,7 +38,9 @@ struct Lane {
     std::condition_variable cv_work, cv_done;
     std::deque<Request> q;
     std::vector<hipEvent_t> free_events;
-    uint64_t next_seq = 1, done_seq = 0;
+    uint64_t next_seq = 1, done_seq = 0;   // every seq <= done_seq has completed ...
+    std::set<uint64_t> done_ahead;         // ... and so have these (served ahead of an unready predecessor)
+    bool is_done(uint64_t seq) const { return seq <= done_seq || done_ahead.count(seq) != 0; }
     bool stop = false;
 };
 
@@ -57,13 +64,19 @@ struct uwip_copier {
         if (e != hipSuccess) fail("hipSetDevice (copy lane)", e);
         for (;;) {
             Request r;
+            bool ready = false;
             {
                 std::unique_lock<std::mutex> lk(L.mu);
                 L.cv_work.wait(lk, [&] { return L.stop || !L.q.empty(); });
                 if (L.q.empty()) return;                    // stop requested and nothing left
-                r = L.q.front();
+                // the first queued request that can run now; none: the head, and sleep on its dependency
+                size_t pick = 0;
+                for (size_t i = 0; i < L.q.size(); ++i)
+                    if (!L.q[i].after || hipEventQuery(L.q[i].after) == hipSuccess) { pick = i; ready = true; break; }
+                r = L.q[pick];
+                L.q.erase(L.q.begin() + (std::ptrdiff_t)pick);
             }
-            if (r.after) {
+            if (r.after && !ready) {
                 e = hipEventSynchronize(r.after);
                 if (e != hipSuccess) fail("hipEventSynchronize (copy dependency)", e);
             }
@@ -74,9 +87,12 @@ struct uwip_copier {
             }
             {
                 std::lock_guard<std::mutex> lk(L.mu);
-                L.q.pop_front();
                 if (r.after) L.free_events.push_back(r.after);
-                L.done_seq = r.seq;
+                L.done_ahead.insert(r.seq);
+                while (!L.done_ahead.empty() && *L.done_ahead.begin() == L.done_seq + 1) {
+                    L.done_seq++;
+                    L.done_ahead.erase(L.done_ahead.begin());
+                }
             }
             L.cv_done.notify_all();
         }
@@ -121,7 +137,10 @@ UWIP_API int uwip_copier_create(int device, uwip_copier **out)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return UWIP_ERR_HIP;
     if (device < 0 || device >= n) return UWIP_ERR_INVALID;
+    int caller_dev = 0;
+    (void)hipGetDevice(&caller_dev);
     if (hipSetDevice(device) != hipSuccess) return UWIP_ERR_HIP;
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{caller_dev};   // the caller's current device is left as found
     uwip_copier *c = new (std::nothrow) uwip_copier();
     if (!c) return UWIP_ERR_NOMEM;
     c->device = device;
@@ -146,7 +165,10 @@ UWIP_API int uwip_copier_destroy(uwip_copier *c)
         L.cv_work.notify_all();
     }
     for (auto &L : c->lane) if (L.th.joinable()) L.th.join();       // each lane finishes its queue first
+    int caller_dev = 0;
+    (void)hipGetDevice(&caller_dev);
     (void)hipSetDevice(c->device);
+    struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{caller_dev};
     for (auto &L : c->lane) {
         for (auto ev : L.free_events) (void)hipEventDestroy(ev);
         (void)hipStreamDestroy(L.stream);
@@ -173,7 +195,7 @@ UWIP_API int uwip_copier_wait(uwip_copier *c, uint64_t ticket)
     const uint64_t seq = ticket >> 1;
     std::unique_lock<std::mutex> lk(L.mu);
     if (seq >= L.next_seq) return UWIP_ERR_INVALID;
-    L.cv_done.wait(lk, [&] { return L.done_seq >= seq; });
+    L.cv_done.wait(lk, [&] { return L.is_done(seq); });
     return c->failed.load() ? UWIP_ERR_HIP : UWIP_OK;
 }
 
@@ -185,7 +207,7 @@ UWIP_API int uwip_copier_query(uwip_copier *c, uint64_t ticket, int *done)
     Lane &L = c->lane[ticket & 1];
     std::lock_guard<std::mutex> lk(L.mu);
     if ((ticket >> 1) >= L.next_seq) return UWIP_ERR_INVALID;
-    *done = L.done_seq >= (ticket >> 1) ? 1 : 0;
+    *done = L.is_done(ticket >> 1) ? 1 : 0;
     return c->failed.load() ? UWIP_ERR_HIP : UWIP_OK;
 }
 

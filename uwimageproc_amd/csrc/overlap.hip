@@ -28,7 +28,8 @@ constexpr int DESC_BYTES = 64;     // packed bits
 constexpr int DESC_K = 512;        // unpacked 0/1 bytes for the i8 MFMA
 constexpr int BORDER = 8;
 constexpr float DTHRESH = 0.001f;
-constexpr int MIN_INLIERS = 6;       // a homography supported by fewer inliers is none (-2.0): four chance matches always fit one
+constexpr int MIN_INLIERS = 6;       // default: a homography supported by fewer inliers is none (-2.0): four chance matches always fit one;
+                                     // UWIP_OVERLAP_MIN4 (uwip_overlap_match_ex) lowers it to the reference's 4 (videostrip.cpp:252-272)
 constexpr float KC_REF = 0.5f;       // contrast factor at and above which the detector threshold is DTHRESH itself
 constexpr int RANSAC_ITERS = 512;
 constexpr int TW = 640, TH = 480;  // TARGET_WIDTH / TARGET_HEIGHT (videostrip.hpp:48-49)
@@ -1362,7 +1363,7 @@ __global__ __launch_bounds__(256) void k_ov_geometry(const Keypoint *__restrict_
                                                     const int32_t *__restrict__ qn, const int32_t *__restrict__ tn,
                                                     const int32_t *__restrict__ pair_q, const int32_t *__restrict__ pair_t,
                                                     const int32_t *__restrict__ m_idx, const int32_t *__restrict__ m_dist,
-                                                    int w, int h, int videoW, int videoH, uint32_t seed,
+                                                    int w, int h, int videoW, int videoH, uint32_t seed, int min_inliers,
                                                     float *__restrict__ ratio, int32_t *__restrict__ info /*[P][8]*/,
                                                     double *__restrict__ Hout /*[P][9]*/)
 {
@@ -1453,7 +1454,7 @@ __global__ __launch_bounds__(256) void k_ov_geometry(const Keypoint *__restrict_
         __syncthreads();
     }
     const int best = s_best_cnt[0], best_it = s_best_it[0];
-    if (best < MIN_INLIERS) {                         // H.empty() -> -2.0 (videostrip.cpp:272)
+    if (best < min_inliers) {                         // H.empty() -> -2.0 (videostrip.cpp:272)
         if (tid == 0) ratio[p] = -2.0f;
         return;
     }
@@ -1996,7 +1997,17 @@ UWIP_API int uwip_overlap_match(uwip_ctx *ctx, const uwip_features *fq, const uw
                                 const int32_t *h_pair_t, int npairs, int videoWidth, int videoHeight, uint32_t seed,
                                 float *d_ratio, int32_t *d_info, double *d_H, int32_t *d_match_idx, int32_t *d_match_dist)
 {
+    return uwip_overlap_match_ex(ctx, fq, ft, h_pair_q, h_pair_t, npairs, videoWidth, videoHeight, seed, 0u, d_ratio, d_info, d_H,
+                                 d_match_idx, d_match_dist);
+}
+
+UWIP_API int uwip_overlap_match_ex(uwip_ctx *ctx, const uwip_features *fq, const uwip_features *ft, const int32_t *h_pair_q,
+                                   const int32_t *h_pair_t, int npairs, int videoWidth, int videoHeight, uint32_t seed, unsigned flags,
+                                   float *d_ratio, int32_t *d_info, double *d_H, int32_t *d_match_idx, int32_t *d_match_dist)
+{
     if (int rc_e = uwip_enter(ctx)) return rc_e;
+    UWIP_REQUIRE(ctx, (flags & ~(unsigned)UWIP_OVERLAP_MIN4) == 0, "unknown flag");
+    const int min_inliers = (flags & UWIP_OVERLAP_MIN4) ? 4 : MIN_INLIERS;
     UWIP_REQUIRE(ctx, fq && ft && fq->ctx == ctx && ft->ctx == ctx, "bad feature sets");
     UWIP_REQUIRE(ctx, npairs >= 0 && npairs <= 65535, "npairs out of range");
     if (npairs == 0) return UWIP_OK;
@@ -2031,7 +2042,7 @@ UWIP_API int uwip_overlap_match(uwip_ctx *ctx, const uwip_features *fq, const uw
         int rc = uwip_lds_optin(ctx, "k_ov_geometry", (const void *)k_ov_geometry, lds);
         if (rc) return rc;
         k_ov_geometry<<<npairs, 256, lds, ctx->stream>>>(fq->d_kp, ft->d_kp, fq->d_n, ft->d_n, d_pairs, d_pairs + npairs, m_idx, m_dist,
-                                                        fq->w, fq->h, videoWidth, videoHeight, seed, d_ratio, info, d_H);
+                                                        fq->w, fq->h, videoWidth, videoHeight, seed, min_inliers, d_ratio, info, d_H);
         UWIP_HIP(ctx, hipGetLastError());
     }
     return UWIP_OK;

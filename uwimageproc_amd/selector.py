@@ -114,7 +114,7 @@ class GpuBackend(Backend):
         self.vw, self.vh = video_size
         self.feats = vs.Features(ctx, 1 + max(1, lookahead))
         self.cap = max(1, lookahead)
-        self.key_id = None
+        self.key = None
         self.wh = None
 
     def close(self):
@@ -145,9 +145,9 @@ class GpuBackend(Backend):
                       C.c_void_p(desc.ctypes.data), len(kps))
 
     def overlaps(self, key, objs):
-        if self.key_id is not id(key):
+        if self.key is not key:                              # the key frame's features are uploaded once per key change
             self._upload(0, key)
-            self.key_id = id(key)
+            self.key = key                                   # keeps the record alive, so identity is a sound test
         out = []
         for k in range(0, len(objs), self.cap):
             part = objs[k:k + self.cap]

@@ -59,8 +59,11 @@ class Features:
         return kps[:n.value].copy(), desc[:n.value].copy()
 
 
+OVERLAP_MIN4 = 4          # uwip.h UWIP_OVERLAP_MIN4: the reference's ">= 4 good matches" rule instead of >= 6 inliers
+
+
 def match_pairs(ctx: Context, fq: Features, ft: Features, pair_q, pair_t, vw: int, vh: int, seed: int = 1,
-                want_matches: bool = False):
+                want_matches: bool = False, min4: bool = False):
     """kNN(2) + ratio test + homography + overlapArea for (object slot, key slot) pairs."""
     n = len(pair_q)
     dev = torch.device("cuda", ctx.device)
@@ -72,7 +75,8 @@ def match_pairs(ctx: Context, fq: Features, ft: Features, pair_q, pair_t, vw: in
     pq = (C.c_int32 * n)(*[int(v) for v in pair_q])
     pt = (C.c_int32 * n)(*[int(v) for v in pair_t])
     torch.cuda.synchronize()
-    ctx.call("uwip_overlap_match", fq._h, ft._h, pq, pt, n, int(vw), int(vh), int(seed), C.c_void_p(ratio.data_ptr()),
+    ctx.call("uwip_overlap_match_ex", fq._h, ft._h, pq, pt, n, int(vw), int(vh), int(seed), OVERLAP_MIN4 if min4 else 0,
+             C.c_void_p(ratio.data_ptr()),
              C.c_void_p(info.data_ptr()), C.c_void_p(H.data_ptr()),
              C.c_void_p(midx.data_ptr()) if want_matches else None, C.c_void_p(mdist.data_ptr()) if want_matches else None)
     ctx.sync()
