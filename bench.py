@@ -122,7 +122,7 @@ def paced_stream(args, dev_index, dev, H, W):
             "note": "latency = result downloaded - frame arrival; a frame waits for its batch to fill, then for upload + pipe + download"}
 
 
-def cpu_baseline(H, W):
+def cpu_baseline(H, W, spot=None):
     """The CPU restatement of the same per-frame pipe (kind = "port": the reference's OpenCV / numpy path itself cannot
     be built or imported here), plain C compiled `-O3 -march=native` on this host when gcc is present
     (else the prebuilt -O2 library), at the bench's full frame size:
@@ -150,7 +150,9 @@ def cpu_baseline(H, W):
         build = "gcc -O3 -march=native -ffp-contract=off (built on this host)"
     except Exception:
         orc = _oracle.load()
-    select = uwip_lib().uwip_aclahe_select          # pure host function (MINPACK / spline restatement): CPU code on both sides
+    # the ONE product function inside the CPU baseline: the parameter choice (MINPACK / spline restatement, pure host code,
+    # 0.5 ms of ~2.9 s per frame) -- the oracle has no C form of it (its checker is scipy, tests/_knee_mirror.py)
+    select = uwip_lib().uwip_aclahe_select
 
     def one_frame(idx, timing=None):
         img = synth.uw_stream_motion(idx, 2, H, W)
@@ -180,6 +182,12 @@ def cpu_baseline(H, W):
                            "overlap_s": d[4] / 2 + d[5]})          # d[4] held two detect+describe passes
         return 0
 
+    check = None
+    if spot is not None:
+        try:
+            check = spot_check_vs_oracle(orc, select, spot)
+        except Exception as ex:
+            check = {"ok": False, "error": f"{type(ex).__name__}: {str(ex)[:200]}"}
     parts = {}
     t0 = time.perf_counter()
     one_frame(0, parts)
@@ -201,10 +209,74 @@ def cpu_baseline(H, W):
         walls.append(time.perf_counter() - t1)
     wall = min(walls)
     return {"value": n / wall, "unit": "frames/s", "cores": n, "cores_visible": cores, "cgroup_cpu_quota": quota, "kind": "port",
+            "spot_check_vs_oracle": check,
             "sample": f"{n} frames of {W}x{H}, one per host thread ({cores} CPUs in the affinity mask, cgroup quota "
-                      f"{quota if quota else 'none'}), whole pipe in C ({build}), best of two passes; single thread: 1 frame",
+                      f"{quota if quota else 'none'}), whole pipe in C ({build}), best of two passes; single thread: 1 frame; "
+                      "the ACLAHE parameter choice inside it is the product's own host function uwip_aclahe_select "
+                      "(0.5 ms per frame; the oracle holds no C form of it)",
             "single_thread": {"value": 1.0 / single, "unit": "frames/s", "cores": 1, "seconds_per_frame": single, "parts": parts},
             "all_cores_wall_s": wall, "all_cores_walls_s": walls, "total_cpu_baseline_s": time.perf_counter() - t0}
+
+
+def outputs_identical(rig):
+    """The S sub-batches of a rank hold the same frames (Rig.__init__), so after any number of steps every sub-batch pipe
+    must hold byte-identical enhanced frames, the same ACLAHE parameters and the same overlap ratios: a free check of
+    the 8-stream arrangement the headline is timed on (call after rig.drain())."""
+    p0 = rig.pipes[0]
+    ok = True
+    for p in rig.pipes[1:]:
+        ok = ok and bool(torch.equal(p.work, p0.work)) and bool(torch.equal(p.ratio, p0.ratio)) and list(p.params) == list(p0.params)
+    return ok
+
+
+def spot_capture(rig, dev_index):
+    """What the oracle needs to check one frame of sub-batch 0 of the TIMED arrangement: the input frames, the outputs /
+    parameters / ratios the timed steps left behind, and the device's dehaze output for the same frames (a separate
+    un-chained uwip_dehaze call: the oracle chain is re-synchronised there, because the float64 dehaze agrees to 1e-9
+    and its 8-bit cast only away from exact rounding ties)."""
+    from uwimageproc_amd.pipeline import FramePipe
+    p = rig.pipes[0]
+    n = min(2, rig.Fs)
+    cap = {"frames": rig.parts[0][:n].cpu().numpy().copy(), "out": p.work[:n].cpu().numpy().copy(), "params": list(p.params[:n]),
+           "ratio": p.ratio[:n].cpu().numpy().copy(), "vw": p.vw, "vh": p.vh, "seed": p.seed}
+    with torch.cuda.stream(torch.cuda.Stream(torch.device("cuda", dev_index))):
+        probe = FramePipe(dev_index, n, rig.H, rig.W)
+        probe.stage_dehaze(rig.parts[0][:n])
+        probe.ctx.sync()
+        cap["dehazed"] = probe.work.cpu().numpy().copy()
+        probe.close()
+    return cap
+
+
+def spot_check_vs_oracle(orc, select, cap):
+    """One frame of sub-batch 0 of the timed run against the oracle chain (the checker; never the thing measured)."""
+    import ctypes as C
+    f = len(cap["frames"]) - 1
+    o, _ = orc.dehaze(cap["frames"][f], 15, full=True, guard_s=True)
+    d = np.abs(cap["dehazed"][f].astype(np.int16) - o.astype(np.int16))
+    res = {"frame_of_sub_batch_0": f, "dehaze_max_abs_diff_levels": int(d.max()), "dehaze_frac_bytes_differing": float((d != 0).mean())}
+    st, _ = orc.histretch(cap["dehazed"][f], "RGB")
+    v = orc.bgr_to_v(st)
+    tab = np.ascontiguousarray(orc.sweep(orc.gaussian3(v)), np.float32)
+    bs, cl = C.c_int32(0), C.c_int32(0)
+    select(tab.ctypes.data_as(C.POINTER(C.c_float)), 1, C.byref(bs), C.byref(cl), None)
+    res["params_device"] = [int(x) for x in cap["params"][f]]
+    res["params_from_oracle_table"] = [bs.value, cl.value]
+    res["params_equal"] = res["params_device"] == res["params_from_oracle_table"]
+    b_, c_ = cap["params"][f]
+    e = orc.hsv_replace_v(st, orc.clahe(v, float(c_), int(b_), int(b_)))
+    res["output_equal"] = bool(np.array_equal(e, cap["out"][f]))
+    if f >= 1:
+        er, _, _ = orc.calcOverlap(cap["out"][f - 1], cap["out"][f], cap["vw"], cap["vh"], seed=cap["seed"])
+        res["overlap_ratio_device"] = float(cap["ratio"][f])
+        res["overlap_ratio_oracle"] = float(er)
+        res["overlap_abs_err"] = abs(float(cap["ratio"][f]) - float(er))
+    res["ok"] = bool(res["dehaze_max_abs_diff_levels"] <= 1 and res["dehaze_frac_bytes_differing"] <= 1e-2 and res["params_equal"]
+                     and res["output_equal"] and res.get("overlap_abs_err", 0.0) <= 1e-6)
+    res["note"] = ("dehaze: device bytes vs the C oracle (<= 1 level at rounding ties); from the device's dehazed bytes on: histretch, "
+                   "V, blur, 255-evaluation sweep table -> parameter choice, CLAHE, HSV merge byte-exact; overlap ratio of the "
+                   "device's frames f-1, f recomputed by the oracle (1e-6)")
+    return res
 
 
 I8_MFMA_PEAK_TOPS = 5000.0     # dense i8 = 2x the ~2.5 PFLOP/s dense BF16 rate (MI355X_MICROARCH.md, Matrix cores)
@@ -240,7 +312,7 @@ def stage_of(kernel):
 def pmc_entry(kernel, rows, cols):
     """Committed counter digest of the same command (tools/pmc_digest.py over separate rocprofv3 --pmc passes; the
     counters cannot be read inside this process).  None when no matching profile is committed."""
-    for name in ("r03_pmc.json", "r02_pmc.json"):
+    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             e = d.get(f"{cols}x{rows}", {}).get(kernel)
@@ -281,12 +353,45 @@ def matcher_report(ctx, dev, pairs=64):
     avg = ms / cnt
     ops = 2.0 * K * K * 512 * pairs
     tops = ops / (avg * 1e-3) / 1e12
-    return {"kernel": "k_ov_match", "workload": f"{pairs} pairs x ({K} x {K}) 512-bit descriptors (config 4)", "ops_per_launch": ops,
-            "avg_launch_ms": avg, "achieved": tops, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": tops / I8_MFMA_PEAK_TOPS,
-            "bound": "mfma"}
+    out = {"kernel": "k_ov_match", "workload": f"{pairs} pairs x ({K} x {K}) 512-bit descriptors (config 4)", "ops_per_launch": ops,
+           "avg_launch_ms": avg, "achieved": tops, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": tops / I8_MFMA_PEAK_TOPS,
+           "bound": "mfma"}
+    try:                                                     # MFMA counters of the committed rocprofv3 --pmc pass of tools/matcher_only.py
+        out["mfma_counters"] = json.load(open(os.path.join(ROOT, "profiles", "r04_matcher_pmc.json")))
+    except Exception:
+        out["mfma_counters"] = None
+    return out
+
+
+def hbm_copy_rate(ctx, dev):
+    """Measured copy bandwidth of this chip beside the nominal 8 TB/s: the library's own streaming
+    kernel (k_apply_lut with identity tables: 16 B per lane, read + write in place) on a 1 GB buffer."""
+    import ctypes as C
+    from uwimageproc_amd import batch_of
+    F, H, W = 162, 1080, 1920                                 # 162 x 6.22 MB = 1.008 GB
+    buf = torch.randint(0, 256, (F, H, W, 3), dtype=torch.uint8, device=dev)
+    lut = torch.arange(256, dtype=torch.uint8, device=dev).repeat(F, 3, 1).contiguous()
+    b = batch_of(buf)
+    ctx.call("uwip_apply_lut", C.byref(b), C.c_void_p(lut.data_ptr()))
+    ctx.sync()
+    ctx.prof_reset(); ctx.prof_enable(True)
+    for _ in range(5):
+        ctx.call("uwip_apply_lut", C.byref(b), C.c_void_p(lut.data_ptr()))
+    ctx.sync()
+    r = ctx.prof_results()
+    ctx.prof_enable(False)
+    ms, cnt = r["k_apply_lut"]
+    nbytes = 2.0 * buf.numel()
+    del buf, lut
+    return {"GBps": nbytes / (ms / cnt * 1e-3) / 1e9, "bytes_moved_per_launch": nbytes, "avg_launch_ms": ms / cnt,
+            "kernel": "k_apply_lut (identity tables, in place: 1.008 GB read + 1.008 GB written per launch)"}
 
 
 def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
+    """roofline = the kernel with the largest share of the step (what the contract calls the dominant kernel), priced
+    against the limit that binds it, with its HBM reading beside it; roofline.clahe_kernel = north_star's CLAHE kernel
+    (the bilinear apply); roofline.clahe_whole = all kernels of one cv::CLAHE::apply against SURVEY 8(d)'s 3N bytes for
+    the five grids of the sweep on the pipe's own V planes; roofline.matcher = k_ov_match against the dense i8 MFMA peak."""
     import ctypes as C
     from uwimageproc_amd import batch_of
     N = H * W
@@ -299,10 +404,11 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
     torch.cuda.synchronize()
     res = ctx.prof_results()
     ctx.prof_enable(False)
-    kernels = {k: {"ms_per_step": ms / nprof, "launches_per_step": cnt / nprof, "stage": stage_of(k)} for k, (ms, cnt) in res.items()}
+    # one pass of sub-batch 0 = Fs frames on one stream; the step is S such passes on S streams
+    kernels = {k: {"ms_per_subbatch": ms / nprof, "launches_per_subbatch": cnt / nprof, "stage": stage_of(k)} for k, (ms, cnt) in res.items()}
     if "k_clahe_apply" not in res:
         return None, kernels
-    tot = sum(v["ms_per_step"] for v in kernels.values())
+    tot = sum(v["ms_per_subbatch"] for v in kernels.values())
 
     def hbm_entry(kernel, bytes_per_frame, frames_per_launch, ms, cnt):
         avg_ms = ms / cnt
@@ -312,22 +418,76 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
         traffic = None if e is None else e["hbm_bytes_per_frame"] * frames_per_launch
         return {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else traffic / per_launch,
-                "traffic_source": None if e is None else "committed rocprofv3 --pmc passes of the same command (profiles/r03_pmc.json: "
+                "traffic_source": None if e is None else "committed rocprofv3 --pmc passes of the same command (profiles/*_pmc.json: "
                                   "2 x FETCH_SIZE + WRITE_SIZE per launch), not re-measured in this run",
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch}
 
-    # (1) the CLAHE kernel named by north_star: the final per-frame apply (read N + write N per frame), as launched
+    # (1) the kernel with the largest share of the step
+    dom_name = max(kernels.items(), key=lambda kv: kv[1]["ms_per_subbatch"])[0]
+    dms, dcnt = res[dom_name]
+    if dom_name.startswith("k_clahe_sweep"):
+        # SURVEY 8(d): the sweep's algorithmic minimum is one read of the V plane per grid-size launch = N per frame
+        hb = hbm_entry(dom_name, 1.0 * N, Fs, dms, dcnt)        # every grid-size launch covers the whole sub-batch
+        hb["algorithmic_note"] = "8(d): one read of the V plane per grid size (N B per frame per launch)"
+    elif dom_name.startswith("k_gf_ws_solve"):
+        hb = hbm_entry(dom_name, (3 + 5 + 48) * N, Fs, dms, dcnt)
+        hb["algorithmic_note"] = ("per frame, averaged over the two launches of a step (filter 1: guide 3N + two 8-bit p planes 2N read, "
+                                  "64N written; filter 3: 3N + 8N read, 32N written)")
+    elif dom_name.startswith("k_gf_ws_final"):
+        hb = hbm_entry(dom_name, (48 + 3 + 12) * N, Fs, dms, dcnt)
+        hb["algorithmic_note"] = "per frame, averaged over the two launches of a step (filter 1: 64N + 3N read, 16N written; filter 3: 32N + 3N, 8N)"
+    else:
+        hb = {"bound": "hbm", "kernel": dom_name, "avg_launch_ms": dms / dcnt, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+              "frac": None, "traffic": None}
+    e = pmc_entry(dom_name, H, W)
+    valu = lds = None
+    if e is not None and e.get("valu_insts_per_frame"):
+        ginstr = e["valu_insts_per_frame"] * Fs / ((dms / dcnt) * 1e-3) / 1e9          # every launch covers the whole sub-batch
+        valu = {"wave_instr_per_launch": e["valu_insts_per_frame"] * Fs, "achieved_Ginstr_per_s": ginstr,
+                "peak_Ginstr_per_s": VALU_PEAK_GINSTR, "frac": ginstr / VALU_PEAK_GINSTR,
+                "spec_peak_Ginstr_per_s": VALU_SPEC_GINSTR, "frac_of_spec": ginstr / VALU_SPEC_GINSTR,
+                "mean_ns_per_instr_per_simd": 1024.0 / ginstr,
+                "source": "SQ_INSTS_VALU of the committed rocprofv3 --pmc pass (profiles/), time from this run.  peak = the "
+                          "measured issue rate of plain f32 operations (one per 1.14 ns per SIMD, tools/ubench/valu_rate.hip); "
+                          "the kernel's mix also holds v_cvt_f32_ubyte / v_cvt_pk_u8_f32 / v_lshl_add at 1.83 ns, so "
+                          "mean_ns_per_instr_per_simd against 1.14 .. 1.83 says how busy the issue port is; spec_peak = one "
+                          "wave64 f32 instruction per 2 clocks at 2.4 GHz (128 FMA lanes per CU and clock)"}
+    if e is not None and e.get("lds_idx_active_per_frame"):
+        # the LDS pipe of a CU beside the issue ports: SQ_LDS_IDX_ACTIVE summed over the 256 CUs, 2.4 GHz
+        cyc_cu = e["lds_idx_active_per_frame"] * Fs / 256.0
+        lds = {"idx_active_cycles_per_cu_per_launch": cyc_cu, "busy_frac": cyc_cu / ((dms / dcnt) * 1e-3 * 2.4e9),
+               "bank_conflict_frac_of_active": e.get("lds_bank_conflict_per_frame", 0.0) / e["lds_idx_active_per_frame"],
+               "source": "SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT of the committed --pmc pass, time from this run"}
+    if dom_name.startswith("k_clahe_sweep") and valu is not None:
+        # the sweep is bound by VALU issue (and the LDS pipe), not by HBM: price it there, keep the HBM reading beside it
+        roof = {"bound": "valu", "kernel": dom_name, "achieved": valu["achieved_Ginstr_per_s"], "peak": VALU_PEAK_GINSTR,
+                "unit": "G wave-instr/s", "frac": valu["frac"], "traffic": hb.get("traffic"),
+                "traffic_over_algorithmic": hb.get("traffic_over_algorithmic"), "avg_launch_ms": dms / dcnt,
+                "hbm": hb, "hbm_frac": hb.get("frac"), "valu": valu, "lds": lds,
+                "bound_note": "the histogram sweep evaluates up to 255 CLAHE outputs per pixel from one read of the plane: VALU issue "
+                              "and the LDS pipe bind it; `hbm` prices the same launch against SURVEY 8(d)'s N bytes per frame"}
+    else:
+        roof = dict(hb)
+        roof["valu"], roof["lds"] = valu, lds
+    roof["ms_per_subbatch"] = kernels[dom_name]["ms_per_subbatch"]
+    roof["share_of_step"] = kernels[dom_name]["ms_per_subbatch"] / tot
+    roof["is"] = "the kernel with the largest share of the step's kernel time"
+
+    # (2) the CLAHE kernel named by north_star: the final per-frame apply (read N + write N per frame), as launched
     # by the step (one launch per 64-frame sub-batch: 265 MB at 1080p, about the size of the 256 MB Infinity Cache)
     ms, cnt = res["k_clahe_apply"]
-    roof = hbm_entry("k_clahe_apply", 2.0 * N, Fs * nprof / cnt, ms, cnt)
-    roof["working_set"] = "one sub-batch launch of the step (input V written by the preceding pass; may hit in the Infinity Cache)"
-    # (1b) the same kernel on a working set the Infinity Cache cannot hold: ONE launch over >= 1 GB (V in + out of 256
-    # 1080p frames = 1.06 GB), input last touched a whole buffer ago
+    ck = hbm_entry("k_clahe_apply", 2.0 * N, Fs * nprof / cnt, ms, cnt)
+    ck["working_set"] = "one sub-batch launch of the step (input V written by the preceding pass; may hit in the Infinity Cache)"
+    ck["share_of_step"] = kernels["k_clahe_apply"]["ms_per_subbatch"] / tot
+    roof["clahe_kernel"] = ck
+    # (2b) the same kernel on a working set the Infinity Cache cannot hold: ONE launch over >= 1 GB (V in + out of 256
+    # 1080p frames = 1.06 GB), input last touched a whole buffer ago; the pipe's own V planes, repeated
     big_f = max(Fs, int(np.ceil(1.0e9 / (2.0 * N))))
     try:
         if not args.large_ws:
             raise RuntimeError("skipped (--no-large-working-set)")
-        vin = torch.randint(0, 256, (big_f, H, W), dtype=torch.uint8, device=dev)
+        vown = pipe.v                                         # the V planes of sub-batch 0 (left by stage_aclahe)
+        vin = vown.repeat((big_f + Fs - 1) // Fs, 1, 1)[:big_f].contiguous()
         vout = torch.empty_like(vin)
         ib, ob = batch_of(vin), batch_of(vout)
         ctx.call("uwip_clahe", C.byref(ib), C.byref(ob), C.c_double(3.0), 8, 8, 0)    # warm-up: tables, workspaces
@@ -341,12 +501,12 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
         ms2, cnt2 = r2["k_clahe_apply"]
         big = hbm_entry("k_clahe_apply", 2.0 * N, big_f, ms2, cnt2)
         big["working_set"] = f"one launch over {big_f} frames = {2.0 * N * big_f / 1e9:.2f} GB (> 256 MB Infinity Cache), CLAHE(3.0, 8x8)"
-        roof["large_working_set"] = big
+        ck["large_working_set"] = big
 
-        # (1c) SURVEY 8(d)'s "CLAHE kernel" is the whole apply of cv::CLAHE: 3N = read N (tile histograms) + read N + write N
-        # (interpolation).  All kernels of one uwip_clahe call: tile histograms + clip / LUT + pack + interpolation.
+        # (2c) SURVEY 8(d)'s "CLAHE kernel" is the whole apply of cv::CLAHE: 3N = read N (tile histograms) + read N + write N
+        # (interpolation).  All kernels of one uwip_clahe call: tile histograms + clip / LUT + interpolation.
         def whole(r, frames, label):
-            parts = {k: r[k][0] / r[k][1] for k in ("k_clahe_tilehist", "k_clahe_lut", "k_clahe_pack", "k_clahe_apply") if k in r}
+            parts = {k: r[k][0] / r[k][1] for k in r if k.startswith("k_clahe_")}
             t_ms = sum(parts.values())
             ach = 3.0 * N * frames / (t_ms * 1e-3) / 1e9
             return {"bound": "hbm", "kernels": {k: v * 1e3 for k, v in parts.items()}, "kernel_time_unit": "us per launch", "frames": frames,
@@ -357,7 +517,7 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
         vs = vin[:Fs]
         vo = vout[:Fs]
         ib, ob = batch_of(vs), batch_of(vo)
-        for g_ in (8, 32):
+        for g_ in (2, 4, 8, 16, 32):
             ctx.call("uwip_clahe", C.byref(ib), C.byref(ob), C.c_double(3.0), g_, g_, 0)
             ctx.sync()
             ctx.prof_reset(); ctx.prof_enable(True)
@@ -366,61 +526,32 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
             ctx.sync()
             r3 = ctx.prof_results()
             ctx.prof_enable(False)
-            per_grid[f"{g_}x{g_}"] = whole(r3, Fs, f"uwip_clahe(3.0, {g_}x{g_}) on {Fs} frames (one sub-batch)")
+            per_grid[f"{g_}x{g_}"] = whole(r3, Fs, f"uwip_clahe(3.0, {g_}x{g_}) on the {Fs} V planes of sub-batch 0 (one call)")
         roof["clahe_whole"] = {"large_working_set": whole_big, "sub_batch": per_grid}
         del vin, vout, vs, vo
     except Exception as e:                                    # never lose the bench line over the side measurement
-        roof["large_working_set"] = {"error": str(e)[:200]}
-    # (2) the kernel with the largest share of the step
-    dom_name = max(kernels.items(), key=lambda kv: kv[1]["ms_per_step"])[0]
-    dms, dcnt = res[dom_name]
-    if dom_name == "k_clahe_sweep":
-        # SURVEY 8(d): the sweep's algorithmic minimum is one read of the V plane per grid-size launch = N per frame
-        dom = hbm_entry(dom_name, 1.0 * N, Fs, dms, dcnt)        # every grid-size launch covers the whole sub-batch
-        dom["algorithmic_note"] = "8(d): one read of the V plane per grid size (N B per frame per launch); the kernel is VALU-issue bound, not HBM bound"
-    elif dom_name.startswith("k_gf_ws_solve"):
-        dom = hbm_entry(dom_name, (3 + 5 + 48) * N, Fs, dms, dcnt)
-        dom["algorithmic_note"] = "per frame, averaged over the two launches of a step (filter 1: guide 3N + two 8-bit p planes 2N read, 64N written; filter 3: 3N + 8N read, 32N written)"
-    else:
-        dom = {"kernel": dom_name, "avg_launch_ms": dms / dcnt}
-    dom["ms_per_step"] = kernels[dom_name]["ms_per_step"]
-    dom["share_of_step"] = kernels[dom_name]["ms_per_step"] / tot
-    e = pmc_entry(dom_name, H, W)
-    if e is not None and e.get("valu_insts_per_frame"):
-        ginstr = e["valu_insts_per_frame"] * Fs / ((dms / dcnt) * 1e-3) / 1e9          # every launch covers the whole sub-batch
-        dom["valu"] = {"wave_instr_per_launch": e["valu_insts_per_frame"] * Fs, "achieved_Ginstr_per_s": ginstr,
-                       "peak_Ginstr_per_s": VALU_PEAK_GINSTR, "frac": ginstr / VALU_PEAK_GINSTR,
-                       "spec_peak_Ginstr_per_s": VALU_SPEC_GINSTR, "frac_of_spec": ginstr / VALU_SPEC_GINSTR,
-                       "mean_ns_per_instr_per_simd": 1024.0 / ginstr,
-                       "source": "SQ_INSTS_VALU of the committed rocprofv3 --pmc pass (profiles/), time from this run.  peak = the "
-                                 "measured issue rate of plain f32 operations (one per 1.14 ns per SIMD, tools/ubench/valu_rate.hip); "
-                                 "the kernel's mix also holds v_cvt_f32_ubyte / v_cvt_pk_u8_f32 / v_lshl_add at 1.83 ns, so "
-                                 "mean_ns_per_instr_per_simd against 1.14 .. 1.83 says how busy the issue port is; spec_peak = one "
-                                 "wave64 f32 instruction per 2 clocks at 2.4 GHz (128 FMA lanes per CU and clock)"}
-    if e is not None and e.get("lds_idx_active_per_frame"):
-        # the LDS pipe of a CU beside the issue ports: SQ_LDS_IDX_ACTIVE summed over the 256 CUs, 2.4 GHz
-        cyc_cu = e["lds_idx_active_per_frame"] * Fs / 256.0
-        dom["lds"] = {"idx_active_cycles_per_cu_per_launch": cyc_cu, "busy_frac": cyc_cu / ((dms / dcnt) * 1e-3 * 2.4e9),
-                      "bank_conflict_frac_of_active": e.get("lds_bank_conflict_per_frame", 0.0) / e["lds_idx_active_per_frame"],
-                      "source": "SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT of the committed --pmc pass, time from this run: the histogram "
-                                "atomics (neighbouring pixels share bins) keep the LDS pipe about as busy as the VALU ports"}
-    roof["dominant"] = dom
+        ck["large_working_set"] = {"error": str(e)[:200]}
+    try:
+        roof["hbm_copy_measured"] = hbm_copy_rate(ctx, dev)
+        roof["hbm_copy_measured_GBps"] = roof["hbm_copy_measured"]["GBps"]
+    except Exception as e:
+        roof["hbm_copy_measured"] = {"error": str(e)[:200]}
     # (3) per stage: kernel time against the stage's 8(d) algorithmic bytes
     stages = {}
     for k, v in kernels.items():
-        st = stages.setdefault(v["stage"], {"ms_per_step": 0.0})
-        st["ms_per_step"] += v["ms_per_step"]
+        st = stages.setdefault(v["stage"], {"ms_per_subbatch": 0.0})
+        st["ms_per_subbatch"] += v["ms_per_subbatch"]
     for name, st in stages.items():
-        st["share_of_step"] = st["ms_per_step"] / tot
+        st["share_of_step"] = st["ms_per_subbatch"] / tot
         if name in STAGE_BYTES_PER_PIXEL:
             by = STAGE_BYTES_PER_PIXEL[name] * N * Fs
-            st["algorithmic_bytes_per_step"] = by
-            st["achieved_GBps"] = by / (st["ms_per_step"] * 1e-3) / 1e9
+            st["algorithmic_bytes_per_subbatch"] = by
+            st["achieved_GBps"] = by / (st["ms_per_subbatch"] * 1e-3) / 1e9
             st["frac_of_hbm_peak"] = st["achieved_GBps"] / HBM_PEAK_GBS
     roof["stages"] = stages
-    roof["step_kernel_ms"] = tot
-    top = sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])[:3]
-    roof["largest_kernels"] = [{"kernel": k, "ms_per_step": v["ms_per_step"], "share": v["ms_per_step"] / tot} for k, v in top]
+    roof["subbatch_kernel_ms"] = tot
+    top = sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_subbatch"])[:3]
+    roof["largest_kernels"] = [{"kernel": k, "ms_per_subbatch": v["ms_per_subbatch"], "share": v["ms_per_subbatch"] / tot} for k, v in top]
     # (4) the matcher against the dense i8 MFMA peak: at the step's own keypoint counts and on a full 2048 x 2048 set
     if "k_ov_match" in res:
         info = pipe.info.cpu().numpy()
@@ -556,12 +687,15 @@ def timed(rig, world, steps, warmup, host):
     rig.drain()
     barrier(world)
     torch.cuda.synchronize()
+    c0 = time.process_time()                      # CPU seconds of ALL threads of this rank (sub-batch threads, copier lanes, host pool)
     t0 = time.perf_counter()
     run(steps)
     rig.drain()                                   # compute streams and, in host mode, the last downloads
     barrier(world)
     torch.cuda.synchronize()
-    return sharding.max_over_ranks(time.perf_counter() - t0)
+    dt = time.perf_counter() - t0
+    rig.last_host_cpu_s = time.process_time() - c0
+    return sharding.max_over_ranks(dt)
 
 
 def host_leg(rig, world, steps):
@@ -660,14 +794,21 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    from uwimageproc_amd import sharding
     F, H, W = args.frames, args.rows, args.cols
     S = max(1, args.streams)
     rig = Rig(dev_index, dev, F, H, W, S, 1234 + 1000 * rank)        # a different scene per rank, same size
     pipe = rig.pipes[0]
 
     dt = timed(rig, world, args.steps, args.warmup, host=False)
+    host_cpu_s = sharding.max_over_ranks(rig.last_host_cpu_s)
+    # what was timed is also checked: the S sub-batches hold the same frames, so every pipe must hold the same result
+    same_out = sharding.max_over_ranks(0.0 if outputs_identical(rig) else 1.0) == 0.0
+    spot = spot_capture(rig, dev_index) if (rank == 0 and not args.no_cpu_baseline) else None
 
     host = host_leg(rig, world, args.steps) if args.host_buffers else None
+    if host is not None:
+        host["host_cpu_s_per_step"] = sharding.max_over_ranks(rig.last_host_cpu_s) / args.steps
 
     # per-kernel timing pass (HIP events on the launch stream, inside libuwip)
     roof = None
@@ -690,11 +831,12 @@ def main():
         except Exception as ex:                               # a side measurement never loses the line (all ranks take part)
             fourk = {"error": f"{type(ex).__name__}: {str(ex)[:200]}"}
     barrier(world)
+    failed = False
     if rank == 0:
         cpu = None
         if not args.no_cpu_baseline:
             os.sched_setaffinity(0, all_cpus)                 # the CPU baseline may use every core the job was given
-            cpu = cpu_baseline(H, W)
+            cpu = cpu_baseline(H, W, spot)
         total_frames = world * F * args.steps
         line = {
             "metric": "frames/sec whole-node, 1080p full pipe (dehaze+stretch+CLAHE+overlap)" if (H, W) == (1080, 1920)
@@ -707,6 +849,9 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "host_cpu_s_per_step": host_cpu_s / args.steps,
+            "outputs_identical_across_streams": bool(same_out),
+            "spot_check_vs_oracle": None if cpu is None else cpu.get("spot_check_vs_oracle"),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -716,6 +861,11 @@ def main():
                        "workload": f"full pipe bgdehaze->histretch->aclahe->videostrip-overlap on {W}x{H} uchar3 frames",
                        "frames_per_gpu_per_step": F, "streams_per_gpu": S, "stages": stages,
                        "parallelism": f"frame-batch x{world}", "rank0_placement": placement},
+            "check_note": "outputs_identical_across_streams: the sub-batch pipes of a rank hold the same frames, so after the timed "
+                          "steps all must hold byte-identical enhanced frames, ACLAHE parameters and overlap ratios (every rank); "
+                          "spot_check_vs_oracle: one frame of sub-batch 0 of the timed run against the CPU oracle chain (rank 0, inside "
+                          "the cpu_baseline leg); host_cpu_s_per_step: process CPU seconds of all threads of a rank over the timed region "
+                          "/ steps, max over ranks; the exit code is non-zero when a check fails",
             "value_note": "value: frames resident in HBM when the timed region starts (the contract's definition); "
                           "value_end_to_end: every frame uploaded from and downloaded to page-locked host memory inside the "
                           "timed region (the reference's own timed region, histretch.cpp:165-216), same steps, max over ranks",
@@ -727,11 +877,19 @@ def main():
             "kernels": kernels,
         }
         print(json.dumps(line))
+        spot_res = line["spot_check_vs_oracle"]
+        if spot_res is not None and not spot_res.get("ok", False):
+            failed = True
+    if not same_out or (host is not None and not host["downloaded_equals_device"]):
+        failed = True
     if world > 1:
         import torch.distributed as dist
         sys.stdout.flush()
         dist.barrier()                      # rank 0 may still have been busy with the CPU baseline
         dist.destroy_process_group()
+    if failed:
+        sys.stderr.write("bench.py: a self-check failed (outputs_identical_across_streams / spot_check_vs_oracle / downloaded_equals_device)\n")
+        sys.exit(3)
 
 
 if __name__ == "__main__":

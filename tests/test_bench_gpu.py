@@ -37,7 +37,10 @@ def test_bench_self_launches_two_ranks():
     f2 = two["value"] * two["ms_per_step"] / 1e3
     assert abs(f1 - 8) < 1e-6 and abs(f2 - 16) < 1e-6
     assert one["host_buffers"] is not None and one["host_buffers"]["downloaded_equals_device"]
-    assert one["roofline"] is not None and "dominant" in one["roofline"]
+    assert one["roofline"] is not None and one["roofline"]["kernel"].startswith("k_") and "clahe_kernel" in one["roofline"]
+    assert one["outputs_identical_across_streams"] is True and two["outputs_identical_across_streams"] is True
+    assert two["spot_check_vs_oracle"] is not None and two["spot_check_vs_oracle"]["ok"], two["spot_check_vs_oracle"]
+    assert one["host_cpu_s_per_step"] > 0
 
 
 def test_bench_under_torch_distributed_run():
