@@ -77,6 +77,12 @@ int uwip_ctx_create(int device, void *stream, uwip_ctx **out);
  * as bench.py does).  Every entry point makes the context's device current for
  * the calling thread (hipSetDevice) before it allocates, copies or launches. */
 #define UWIP_CTX_STREAM_GIVEN 1u
+/* Host waits.  Wherever the library waits on the host for its stream (uwip_sync, the ACLAHE parameter choice, staging
+ * reuse) the calling thread SLEEPS on a blocking-sync event by default: hipStreamSynchronize spins, and a rank with
+ * eight sub-batch threads then burns eight cores doing nothing (measured: 1.59 CPU-seconds per 0.177 s step), which a
+ * node's CPU quota does not have for eight ranks.  UWIP_CTX_SPIN_WAIT (or the environment variable UWIP_SPIN_WAIT=1)
+ * keeps the spinning wait: a few tens of microseconds less wake-up latency per wait for one core per waiting thread. */
+#define UWIP_CTX_SPIN_WAIT 2u
 int uwip_ctx_create_ex(int device, void *stream, unsigned flags, uwip_ctx **out);
 int uwip_ctx_destroy(uwip_ctx *ctx);
 const char *uwip_last_error(const uwip_ctx *ctx);
@@ -224,6 +230,11 @@ int uwip_aclahe_sweep_hist(uwip_ctx *ctx, const uwip_batch_u8 *src, int residual
  *   [frames][5].  When 2*CL lies outside the swept grid the BS choice falls
  *   back to the last swept clip limit; uwip_aclahe_auto evaluates it exactly. */
 int uwip_aclahe_knee(const float *h_xs49, const float *h_ys49, int32_t *index);
+/* The persistent host pool uwip_aclahe_select spreads its frames over (one per process, created on first use):
+ * its size is the CPU budget of this rank minus the calling thread, at most 16 -- budget = min(CPUs in the affinity
+ * mask, cgroup CPU quota) / ranks on the node (UWIP_RANKS_ON_NODE, else the launcher's LOCAL_WORLD_SIZE, else 1);
+ * UWIP_HOST_THREADS overrides the size.  Any argument may be NULL. */
+int uwip_host_pool_info(int *workers, double *cpu_budget, int *ranks_on_node);
 int uwip_aclahe_select(const float *h_entropy, int frames, int32_t *h_bs, int32_t *h_cl,
                        int32_t *h_knee);
 

@@ -156,6 +156,49 @@ def test_refined_t_and_restored_vs_reference_golden(ctx):
     _oracle.assert_u8_differs_only_at_rounding_ties(res["out"].cpu().numpy(), g["restored"])
 
 
+@pytest.mark.parametrize("case", ["c", "d"])
+def test_device_vs_big_reference_goldens(ctx, case):
+    """The device against the REFERENCE's own outputs on 216x384 and 270x600 frames (tests/golden/dehaze_{c,d}.npz, made by
+    BGDehaze.py itself): whole 81x81 windows in the interior, one / three 176-column strip seams, several row chunks.
+    Golden B injected (tied minima, B-9); refined t, J (= the blue / green channels of `restored`) and restored <= 1e-9,
+    through BOTH device paths: the fused one (transmission table + recovery inside k_gf_ws_final) and the unfused one
+    that materialises the refined t."""
+    from test_oracle_dehaze import _big_cmp
+    g = _gold(f"dehaze_{case}.npz")
+    img = g["img"]
+    fused = bg.dehaze(ctx, _dev(img), 15, full=False, B=_dev(g["B"]), want_float=True)
+    restored = fused["float"].cpu().numpy()[0]
+    assert _big_cmp(g, restored, "restored") <= TOL
+    assert _big_cmp(g, restored[:, :, 0], "J_blue") <= TOL and _big_cmp(g, restored[:, :, 1], "J_green") <= TOL
+    res = bg.dehaze(ctx, _dev(img), 15, full=False, B=_dev(g["B"]), want_refined_t=True, want_float=True)
+    rt = res["refined_t"].cpu().numpy()[0]
+    assert _big_cmp(g, rt[0], "t_blue") <= TOL and _big_cmp(g, rt[1], "t_green") <= TOL
+    assert _big_cmp(g, res["float"].cpu().numpy()[0], "restored") <= TOL
+    # the device's own background light: first-index ties, so its two pixels must attain the reference's minima
+    _, idx = bg.Background_light(ctx, _dev(img), 15, return_index=True)
+    normI = dz.normalize_input(img)
+    mx = [dz._window_reduce(normI[:, :, c], 15, np.maximum).ravel() for c in range(3)]
+    D0, D1 = mx[2] - mx[0], mx[2] - mx[1]
+    i0, i1 = idx.cpu().numpy()[0]
+    assert D0[i0] == D0.min() and D1[i1] == D1.min()
+
+
+def test_device_guided_filter_vs_big_reference_golden(ctx):
+    """guided_filter at 200 x 620, r = 40, against guidedfilter.py's own output.  The device's guide is 8-bit: the random
+    float64 guide of the golden is not representable, so the golden pins the ORACLE (CPU test) and the device is compared
+    with the oracle on the 8-bit quantisation of the same guide; both comparisons at 1e-9."""
+    from test_oracle_dehaze import big_guided_filter_inputs
+    g = _gold("guided_filter_big.npz")
+    I, p = big_guided_filter_inputs(g)
+    guide = np.clip(np.rint(I * 255), 0, 255).astype(np.uint8)
+    guide[0, 0], guide[0, 1] = 0, 255                       # min-max normalisation = /255: the guide the oracle sees is guide/255
+    q = bg.guided_filter(ctx, _dev(guide), _dev(p), int(g["r"]), float(g["eps"])).cpu().numpy()[0]
+    qo = dz.guided_filter(dz.normalize_input(guide), p, int(g["r"]), float(g["eps"]))
+    assert np.abs(q - qo).max() <= TOL
+    # the quantised guide moves q by far less than the filter's own smoothing: the device sits within 2e-2 of the golden
+    assert np.abs(q - g["q"]).max() <= 2e-2
+
+
 @pytest.mark.parametrize("shape,w", [((120, 160), 9), ((96, 128), 15), ((270, 480), 15)])
 def test_rc_correction_end_to_end_vs_oracle(ctx, shape, w):
     img = synth.uw_frame(200 + shape[0], *shape)

@@ -130,3 +130,54 @@ def test_c_oracle_refuses_small_images(orc):
     f.restype = C.c_int
     f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t] + [C.c_void_p] * 6
     assert f(img.ctypes.data, 80, 200, 600, 15, 1, None, None, 0, None, None, None, None, None, None) == -2
+
+
+# ---- the larger reference-generated goldens: interiors with whole 81x81 windows, several strip seams ----
+def _big_cmp(g, a, key):
+    """max |a - golden[key]|; case d stores the two diagonal phases of a stride-2 subsample"""
+    if int(g["subsampled"]):
+        return max(np.abs(a[0::2, 0::2] - g[key + "_p0"]).max(), np.abs(a[1::2, 1::2] - g[key + "_p1"]).max())
+    return np.abs(a - g[key]).max()
+
+
+@pytest.mark.parametrize("case", ["c", "d"])
+def test_big_dehaze_goldens_pin_both_oracles(orc, case):
+    """216x384 and 270x600 frames run through the reference's own BGDehaze.py (tools/make_goldens.py): rows and columns
+    >= 163, so the interior holds pixels whose 81x81 guided-filter window is whole (the 88x100 golden has none), and the
+    widths cross one / three 176-column strip seams of the device kernels.  The golden B is injected (these frames have
+    tied background-light minima, B-9); every float stage of D2-D5 within 1e-9 for the numpy AND the C oracle."""
+    g = _load(f"dehaze_{case}.npz")
+    img, Bref = g["img"], g["B"]
+    assert img.shape[0] >= 163 and img.shape[1] >= 163 + 176
+    normI = dz.normalize_input(img)
+    tb, tg = dz.refined_t(normI, Bref)
+    assert _big_cmp(g, tb, "t_blue") <= 1e-9 and _big_cmp(g, tg, "t_green") <= 1e-9
+    nJb, nJg = dz.dehazed_BG(normI, Bref)
+    assert _big_cmp(g, nJb, "J_blue") <= 1e-9 and _big_cmp(g, nJg, "J_green") <= 1e-9
+    restored = dz.RC_correction(normI, 15, B=Bref)
+    assert _big_cmp(g, restored, "restored") <= 1e-9
+    _, t = orc.dehaze(img, 15, full=False, B=Bref, taps=("refined", "restored"))
+    assert _big_cmp(g, t["refined"][0], "t_blue") <= 1e-9 and _big_cmp(g, t["refined"][1], "t_green") <= 1e-9
+    assert _big_cmp(g, t["restored"], "restored") <= 1e-9
+    assert _big_cmp(g, t["restored"][:, :, 0], "J_blue") <= 1e-9 and _big_cmp(g, t["restored"][:, :, 1], "J_green") <= 1e-9
+    # D1: tie order unspecified (B-9) -- the reference's B must be the mean of two pixels that attain the two minima
+    mx = [dz._window_reduce(normI[:, :, c], 15, np.maximum).ravel() for c in range(3)]
+    D0, D1 = mx[2] - mx[0], mx[2] - mx[1]
+    flat = normI.reshape(-1, 3)
+    c0, c1 = flat[D0 == D0.min()], flat[D1 == D1.min()]
+    assert int(g["tie_counts"][0]) == len(c0) and int(g["tie_counts"][1]) == len(c1)
+    best = min(np.abs((a + b) / 2 - Bref).max() for a in c0 for b in c1)
+    assert best <= 1e-12
+
+
+def big_guided_filter_inputs(g):
+    rng = np.random.default_rng(int(g["seed"]))
+    rows, cols = int(g["rows"]), int(g["cols"])
+    return rng.random((rows, cols, 3)), rng.random((rows, cols))
+
+
+def test_big_guided_filter_golden_pins_both_oracles(orc):
+    g = _load("guided_filter_big.npz")
+    I, p = big_guided_filter_inputs(g)
+    assert np.abs(dz.guided_filter(I, p, int(g["r"]), float(g["eps"])) - g["q"]).max() <= 1e-9
+    assert np.abs(orc.guided_filter(I, p, int(g["r"]), float(g["eps"])) - g["q"]).max() <= 1e-9

@@ -62,6 +62,9 @@ def dehaze_goldens():
                             J_blue=nJb, J_green=nJg, restored=restored, tie_counts=np.array(ties))
         print(name, "B =", B, "ties", ties)
 
+    big_dehaze_goldens(ref)
+    big_guided_filter_golden(refgf)
+
     # guided filter / box filter alone on random data
     rng = np.random.default_rng(42)
     I = rng.random((90, 97, 3))
@@ -71,6 +74,56 @@ def dehaze_goldens():
     q2 = refgf.guided_filter(I[:85, :83], p[:85, :83], 20, 1e-2)
     np.savez_compressed(os.path.join(OUT, "guided_filter.npz"), I=I, p=p, q=q, box=bx, q_r20=q2)
     print("guided filter goldens written")
+
+
+def checker(a):
+    """the two diagonal phases of a stride-2 subsample: [0::2, 0::2] and [1::2, 1::2] (every row and every column of the
+    plane is represented, at a quarter + a quarter of the bytes)"""
+    return a[0::2, 0::2].copy(), a[1::2, 1::2].copy()
+
+
+def big_dehaze_goldens(ref):
+    """frames whose interior holds WHOLE 81x81 guided-filter windows (rows, cols >= 163), whose width
+    crosses a 176-column strip seam of k_gf_ws_* (and, for case d, three of them) and whose height crosses the row-chunk
+    boundaries the kernels split a frame into.  The reference's own BGDehaze.py runs them at ~65 us per pixel and
+    function, so these take a minute.  Stored: img, B, refined t (blue, green), normalised J (blue, green), restored --
+    float64; case d as the two diagonal phases of a stride-2 subsample (file size)."""
+    for name, seed, rows, cols, sub in (("c", 311, 216, 384, False), ("d", 312, 270, 600, True)):
+        w = 15
+        img = tie_free_image(seed, rows, cols)
+        normI = (img - img.min()) / (img.max() - img.min())       # main.py:17
+        B = ref.Background_light(normI, w)
+        tb, tg = ref.refined_t(normI)
+        nJb, nJg = ref.dehazed_BG(normI, w)
+        restored = ref.RC_correction(normI, w)
+        mx = [None] * 3
+        pad = w // 2
+        padded = np.pad(normI, ((pad, pad), (pad, pad), (0, 0)), "constant")
+        from numpy.lib.stride_tricks import sliding_window_view
+        for c in range(3):
+            mx[c] = sliding_window_view(padded[:, :, c], (w, w)).max(axis=(2, 3))
+        D0, D1 = mx[2] - mx[0], mx[2] - mx[1]
+        ties = [int((D0 == D0.min()).sum()), int((D1 == D1.min()).sum())]
+        planes = {"t_blue": tb, "t_green": tg, "J_blue": nJb, "J_green": nJg, "restored": restored}
+        out = {"img": img, "w": w, "B": B, "tie_counts": np.array(ties), "subsampled": np.array(1 if sub else 0)}
+        for k, a in planes.items():
+            if sub:
+                out[k + "_p0"], out[k + "_p1"] = checker(a)
+            else:
+                out[k] = a
+        np.savez_compressed(os.path.join(OUT, f"dehaze_{name}.npz"), **out)
+        print(name, rows, cols, "B =", B, "ties", ties)
+
+
+def big_guided_filter_golden(refgf):
+    """guided_filter at 200 x 620, r = 40 (interior with whole windows, three strip seams); inputs are regenerated from
+    the seed by the tests (numpy's PCG64 stream is stable), only q is stored."""
+    rng = np.random.default_rng(43)
+    I = rng.random((200, 620, 3))
+    p = rng.random((200, 620))
+    q = refgf.guided_filter(I, p, 40, 1e-3)
+    np.savez_compressed(os.path.join(OUT, "guided_filter_big.npz"), seed=43, rows=200, cols=620, r=40, eps=1e-3, q=q)
+    print("guided filter 200x620 golden written")
 
 
 def knee_goldens():
@@ -87,9 +140,28 @@ def knee_goldens():
     from uwimageproc_amd import synth
     orc = _oracle.load()
     tables, idxs = [], []
-    for seed, rows, cols in ((0, 270, 480), (7, 240, 320), (13, 135, 240)):
-        v = orc.bgr_to_v(synth.uw_frame(seed, rows, cols))
-        tab = orc.sweep(v)                       # [5][51], cl = 0, 0.5, ..., 25
+    srcs = [("frame", seed, rows, cols) for seed, rows, cols in ((0, 270, 480), (7, 240, 320), (13, 135, 240))]
+    # tables of the bench's own stream, as the pipe produces them (dehaze -> histretch -> V -> blur -> sweep)
+    srcs += [("bench", k, 1080, 1920) for k in (0, 1, 2, 3, 17, 31, 32, 33, 47, 63)]
+    # ... and curves the reference's curve_fit gives up on (-1: "the reference would raise there")
+    srcs += [("synthetic", k, 0, 0) for k in range(6)]
+    bench_frames = None
+    for kind, seed, rows, cols in srcs:
+        if kind == "frame":
+            v = orc.bgr_to_v(synth.uw_frame(seed, rows, cols))
+            tab = orc.sweep(v)                       # [5][51], cl = 0, 0.5, ..., 25
+        elif kind == "bench":
+            if bench_frames is None:
+                import bench
+                bench_frames = bench.synth_frames(64, rows, cols, 1234)
+            out, _ = orc.dehaze(bench_frames[seed], 15, full=True, guard_s=True)
+            st, _ = orc.histretch(out, "RGB")
+            tab = orc.sweep(orc.gaussian3(orc.bgr_to_v(st)))
+        else:
+            r = np.random.default_rng(900 + seed)
+            base = [np.zeros(51), np.full(51, 7.3), np.linspace(7.9, 3.0, 51), 7.0 + 0.5 * r.standard_normal(51),
+                    np.where(np.arange(51) < 20, 7.5, 2.0), 4.0 + 3.0 * np.sin(np.arange(51) * 0.9)][seed]
+            tab = np.stack([base + 0.01 * g for g in range(5)]).astype(np.float32)
         x = np.arange(51, dtype=np.float32) * 0.5
         row_idx = []
         for gi in range(5):
@@ -105,7 +177,7 @@ def knee_goldens():
                     row_idx.append(-1)
         tables.append(tab)
         idxs.append(row_idx)
-        print("knee", seed, row_idx)
+        print("knee", kind, seed, row_idx)
     np.savez_compressed(os.path.join(OUT, "aclahe_knee.npz"), tables=np.stack(tables), idx=np.array(idxs))
 
 

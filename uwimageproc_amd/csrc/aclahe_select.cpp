@@ -573,15 +573,50 @@ private:
     {
         int want = -1;
         if (const char *e = std::getenv("UWIP_HOST_THREADS")) want = std::atoi(e);
+        budget_ = cpu_budget(&ranks_);
         if (want < 0) {
-            int cpus = 0;
-            cpu_set_t set;
-            if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
-            if (cpus <= 0) cpus = (int)std::thread::hardware_concurrency();
-            want = std::min(16, std::max(0, cpus - 1));
+            // the caller works too, so budget - 1 helpers; never more than 16 (a sub-batch has 64 frames: the selection
+            // is ~0.3 ms each, more threads only add wake-ups)
+            want = std::min(16, std::max(0, (int)std::floor(budget_ + 1e-9) - 1));
         }
         for (int i = 0; i < want; ++i) th_.emplace_back([this] { loop(); });
     }
+    // CPUs this rank may really use: min(affinity mask, cgroup CPU quota) / ranks on the node.  The affinity mask alone
+    // overstates it: the GPU boxes show 256 CPUs in the mask under a cgroup quota of 16, and eight ranks of a node share it.
+    static double cpu_budget(int *ranks_out)
+    {
+        double cpus = 0;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) cpus = CPU_COUNT(&set);
+        if (cpus <= 0) cpus = (double)std::thread::hardware_concurrency();
+        const char *root = std::getenv("UWIP_CGROUP_ROOT");           // tests point this at a fake tree
+        const std::string base = root && *root ? root : "/sys/fs/cgroup";
+        double quota = 0;
+        if (FILE *f = std::fopen((base + "/cpu.max").c_str(), "r")) {          // cgroup v2: "<quota|max> <period>"
+            char q[64] = {0};
+            double per = 0;
+            if (std::fscanf(f, "%63s %lf", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) quota = std::atof(q) / per;
+            std::fclose(f);
+        } else {
+            double q = 0, per = 0;
+            if (FILE *a = std::fopen((base + "/cpu/cpu.cfs_quota_us").c_str(), "r")) { if (std::fscanf(a, "%lf", &q) != 1) q = 0; std::fclose(a); }
+            if (FILE *b = std::fopen((base + "/cpu/cpu.cfs_period_us").c_str(), "r")) { if (std::fscanf(b, "%lf", &per) != 1) per = 0; std::fclose(b); }
+            if (q > 0 && per > 0) quota = q / per;
+        }
+        if (quota > 0 && quota < cpus) cpus = quota;
+        int ranks = 1;
+        for (const char *name : {"UWIP_RANKS_ON_NODE", "LOCAL_WORLD_SIZE"})
+            if (const char *e = std::getenv(name)) { const int v = std::atoi(e); if (v > 0) { ranks = v; break; } }
+        if (ranks_out) *ranks_out = ranks;
+        return std::max(1.0, cpus / ranks);
+    }
+public:
+    int workers() const { return (int)th_.size(); }
+    double budget() const { return budget_; }
+    int ranks() const { return ranks_; }
+private:
+    double budget_ = 1.0;
+    int ranks_ = 1;
     ~HostPool()
     {
         { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
@@ -610,6 +645,15 @@ private:
 };
 
 }  // namespace
+
+UWIP_API int uwip_host_pool_info(int *workers, double *cpu_budget, int *ranks_on_node)
+{
+    HostPool &p = HostPool::get();
+    if (workers) *workers = p.workers();
+    if (cpu_budget) *cpu_budget = p.budget();
+    if (ranks_on_node) *ranks_on_node = p.ranks();
+    return UWIP_OK;
+}
 
 UWIP_API int uwip_aclahe_knee(const float *h_xs49, const float *h_ys49, int32_t *index)
 {

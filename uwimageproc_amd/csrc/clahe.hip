@@ -1118,7 +1118,7 @@ UWIP_API int uwip_clahe_per_frame(uwip_ctx *ctx, const uwip_batch_u8 *src, const
     ApplyFrame *h_desc = (ApplyFrame *)uwip_host_ws(ctx, "clahe.pf.desc", sizeof(ApplyFrame) * (size_t)F);
     ApplyFrame *d_desc = (ApplyFrame *)uwip_ws(ctx, "clahe.pf.desc", sizeof(ApplyFrame) * (size_t)F);
     if (!h_map || !d_map || !h_desc || !d_desc) return UWIP_ERR_NOMEM;
-    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    UWIP_HIP(ctx, uwip_stream_wait(ctx));
     int *h_clip = h_map + F, *d_clip = d_map + F;
     for (int i = 0; i < F; ++i) {
         const int f = order[i];
@@ -1325,7 +1325,7 @@ UWIP_API int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const 
     rc = uwip_aclahe_sweep(ctx, src, residual_rule, d_ent);
     if (rc) return rc;
     UWIP_HIP(ctx, hipMemcpyAsync(h_ent, d_ent, sizeof(float) * 255 * F, hipMemcpyDeviceToHost, ctx->stream));
-    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));            // host decision point (ACLAHE.py:66-129)
+    UWIP_HIP(ctx, uwip_stream_wait(ctx));            // host decision point (ACLAHE.py:66-129)
     int32_t *bs = h_par, *cl = h_par + F, *need = h_par + 2 * F, *valid = h_par + 3 * F;
     float *extra = (float *)(h_par + 4 * F);
     double *clip = (double *)(extra + 5 * F);
@@ -1353,7 +1353,7 @@ UWIP_API int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const 
                 if (rc) return rc;
             }
             UWIP_HIP(ctx, hipMemcpyAsync(extra + (size_t)f * 5, d_e1, sizeof(float) * 5, hipMemcpyDeviceToHost, ctx->stream));
-            UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            UWIP_HIP(ctx, uwip_stream_wait(ctx));
             valid[f] = 1;
         }
         rc = uwip_aclahe_select_internal(h_ent, F, bs, cl, nullptr, need, extra, valid);

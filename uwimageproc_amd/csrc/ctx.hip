@@ -29,11 +29,24 @@ void uwip_trace_range(const uwip_ctx *ctx, const char *kind, const char *name, c
                  ctx ? (const void *)ctx->stream : nullptr, kind, name, p, (const void *)((const char *)p + bytes), bytes);
 }
 
+hipError_t uwip_stream_wait(uwip_ctx *ctx)
+{
+    static const bool env_spin = [] { const char *e = std::getenv("UWIP_SPIN_WAIT"); return e && *e && *e != '0'; }();
+    if (ctx->spin_wait || env_spin) return hipStreamSynchronize(ctx->stream);
+    if (!ctx->wait_ev) {
+        hipError_t e = hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming | hipEventBlockingSync);
+        if (e != hipSuccess) { ctx->wait_ev = nullptr; return e; }
+    }
+    hipError_t e = hipEventRecord(ctx->wait_ev, ctx->stream);
+    if (e != hipSuccess) return e;
+    return hipEventSynchronize(ctx->wait_ev);
+}
+
 UWIP_API int uwip_ctx_create_ex(int device, void *stream, unsigned flags, uwip_ctx **out)
 {
     if (!out) return UWIP_ERR_INVALID;
     *out = nullptr;
-    if (flags & ~(unsigned)UWIP_CTX_STREAM_GIVEN) return UWIP_ERR_INVALID;
+    if (flags & ~(unsigned)(UWIP_CTX_STREAM_GIVEN | UWIP_CTX_SPIN_WAIT)) return UWIP_ERR_INVALID;
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return UWIP_ERR_HIP;  // no CPU fallback
     if (device < 0 || device >= n) return UWIP_ERR_INVALID;
@@ -41,6 +54,7 @@ UWIP_API int uwip_ctx_create_ex(int device, void *stream, unsigned flags, uwip_c
     uwip_ctx *ctx = new (std::nothrow) uwip_ctx();
     if (!ctx) return UWIP_ERR_NOMEM;
     ctx->device = device;
+    ctx->spin_wait = (flags & UWIP_CTX_SPIN_WAIT) != 0;
     if (stream || (flags & UWIP_CTX_STREAM_GIVEN)) {
         // a NULL handle with UWIP_CTX_STREAM_GIVEN is the device's default (null) stream itself
         ctx->stream = (hipStream_t)stream;
@@ -62,9 +76,10 @@ UWIP_API int uwip_ctx_destroy(uwip_ctx *ctx)
 {
     if (!ctx) return UWIP_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)uwip_stream_wait(ctx);
     for (auto &p : ctx->prof_pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    if (ctx->wait_ev) (void)hipEventDestroy(ctx->wait_ev);
     for (auto &kv : ctx->ws) if (kv.second.ptr) (void)hipFree(kv.second.ptr);
     for (auto &kv : ctx->hs) if (kv.second.ptr) (void)hipHostFree(kv.second.ptr);
     for (auto &kv : ctx->tables) if (kv.second.ptr) (void)hipFree(kv.second.ptr);
@@ -78,7 +93,7 @@ UWIP_API const char *uwip_last_error(const uwip_ctx *ctx) { return ctx ? ctx->er
 UWIP_API int uwip_sync(uwip_ctx *ctx)
 {
     if (int rc_e = uwip_enter(ctx)) return rc_e;
-    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    UWIP_HIP(ctx, uwip_stream_wait(ctx));
     return UWIP_OK;
 }
 
@@ -97,7 +112,7 @@ UWIP_API int uwip_free(uwip_ctx *ctx, void *d_ptr)
 {
     if (int rc_e = uwip_enter(ctx)) return rc_e;
     if (!d_ptr) return UWIP_OK;
-    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    UWIP_HIP(ctx, uwip_stream_wait(ctx));
     UWIP_HIP(ctx, hipFree(d_ptr));
     return UWIP_OK;
 }
@@ -107,7 +122,7 @@ UWIP_API int uwip_memcpy_h2d(uwip_ctx *ctx, void *d_dst, const void *h_src, size
     if (int rc_e = uwip_enter(ctx)) return rc_e;
     if (bytes == 0) return UWIP_OK;
     UWIP_HIP(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
-    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    UWIP_HIP(ctx, uwip_stream_wait(ctx));
     return UWIP_OK;
 }
 
@@ -116,7 +131,7 @@ UWIP_API int uwip_memcpy_d2h(uwip_ctx *ctx, void *h_dst, const void *d_src, size
     if (int rc_e = uwip_enter(ctx)) return rc_e;
     if (bytes == 0) return UWIP_OK;
     UWIP_HIP(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    UWIP_HIP(ctx, uwip_stream_wait(ctx));
     return UWIP_OK;
 }
 
@@ -135,7 +150,7 @@ UWIP_API int uwip_host_free(uwip_ctx *ctx, void *h_ptr)
 {
     if (int rc_e = uwip_enter(ctx)) return rc_e;
     if (!h_ptr) return UWIP_OK;
-    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));   // copies still queued on this context's stream
+    UWIP_HIP(ctx, uwip_stream_wait(ctx));   // copies still queued on this context's stream
     UWIP_HIP(ctx, hipHostFree(h_ptr));
     return UWIP_OK;
 }
@@ -164,7 +179,7 @@ void *uwip_ws(uwip_ctx *ctx, const char *name, size_t bytes)
     if (b.bytes >= bytes && b.ptr) return b.ptr;
     if (b.ptr) {
         // grow: the old buffer may still be in use by queued kernels
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)uwip_stream_wait(ctx);
         (void)hipFree(b.ptr);
         b.ptr = nullptr; b.bytes = 0;
     }
@@ -185,7 +200,7 @@ void *uwip_host_ws(uwip_ctx *ctx, const char *name, size_t bytes)
     uwip_ws_buf &b = ctx->hs[name];
     if (b.bytes >= bytes && b.ptr) return b.ptr;
     if (b.ptr) {
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)uwip_stream_wait(ctx);
         (void)hipHostFree(b.ptr);
         b.ptr = nullptr; b.bytes = 0;
     }
@@ -220,7 +235,7 @@ const void *uwip_table_put(uwip_ctx *ctx, const std::string &key, const void *ho
     // on the context's own stream (not the null stream, which another thread may be using), and drained before
     // `host` -- usually a local std::vector of the caller -- goes away
     if (bytes && (hipMemcpyAsync(b.ptr, host, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-                  hipStreamSynchronize(ctx->stream) != hipSuccess)) {
+                  uwip_stream_wait(ctx) != hipSuccess)) {
         (void)hipFree(b.ptr);
         ctx->fail(UWIP_ERR_HIP, "table upload");
         return nullptr;
@@ -280,7 +295,7 @@ uwip_kscope::~uwip_kscope()
 int uwip_prof_flush(uwip_ctx *ctx)
 {
     if (ctx->prof_pending.empty()) return UWIP_OK;
-    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    UWIP_HIP(ctx, uwip_stream_wait(ctx));
     for (auto &p : ctx->prof_pending) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {

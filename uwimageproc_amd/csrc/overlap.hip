@@ -1831,7 +1831,7 @@ UWIP_API int uwip_features_destroy(uwip_features *f)
 {
     if (!f) return UWIP_OK;
     (void)hipSetDevice(f->ctx->device);
-    (void)hipStreamSynchronize(f->ctx->stream);
+    (void)uwip_stream_wait(f->ctx);
     (void)hipFree(f->d_kp); (void)hipFree(f->d_desc); (void)hipFree(f->d_bits); (void)hipFree(f->d_pop); (void)hipFree(f->d_n);
     delete f;
     return UWIP_OK;
@@ -1900,7 +1900,7 @@ UWIP_API int uwip_features_download(uwip_ctx *ctx, const uwip_features *feats, i
     if (!ctx || !feats) return UWIP_ERR_INVALID;
     if (int rc_e = uwip_enter(ctx)) return rc_e;
     UWIP_REQUIRE(ctx, slot >= 0 && slot < feats->capacity, "slot out of range");
-    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    UWIP_HIP(ctx, uwip_stream_wait(ctx));
     if (h_count) UWIP_HIP(ctx, hipMemcpy(h_count, feats->d_n + slot, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (h_kps) UWIP_HIP(ctx, hipMemcpy(h_kps, feats->d_kp + (size_t)slot * MAXKP, sizeof(Keypoint) * MAXKP, hipMemcpyDeviceToHost));
     if (h_desc) UWIP_HIP(ctx, hipMemcpy(h_desc, feats->d_desc + (size_t)slot * MAXKP * DESC_BYTES, (size_t)MAXKP * DESC_BYTES, hipMemcpyDeviceToHost));
@@ -1944,7 +1944,7 @@ UWIP_API int uwip_features_upload(uwip_ctx *ctx, uwip_features *feats, int slot,
     feats->w = cols; feats->h = rows;
     uint8_t *stage = (uint8_t *)uwip_ws(ctx, "ov.upload.desc", (size_t)MAXKP * DESC_BYTES);
     if (!stage) return UWIP_ERR_NOMEM;
-    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    UWIP_HIP(ctx, uwip_stream_wait(ctx));
     if (count) {
         UWIP_HIP(ctx, hipMemcpy(stage, h_desc, (size_t)count * DESC_BYTES, hipMemcpyHostToDevice));
         UWIP_HIP(ctx, hipMemcpy(feats->d_kp + (size_t)slot * MAXKP, h_kps, sizeof(Keypoint) * (size_t)count, hipMemcpyHostToDevice));
@@ -1954,7 +1954,7 @@ UWIP_API int uwip_features_upload(uwip_ctx *ctx, uwip_features *feats, int slot,
     k_ov_unpack_desc<<<MAXKP, 256, 0, ctx->stream>>>(stage, count, feats->d_bits + (size_t)slot * MAXKP * DESC_K,
                                                      feats->d_pop + (size_t)slot * MAXKP);
     UWIP_HIP(ctx, hipGetLastError());
-    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    UWIP_HIP(ctx, uwip_stream_wait(ctx));
     return UWIP_OK;
 }
 
@@ -1971,7 +1971,7 @@ UWIP_API int uwip_overlap_debug_level(uwip_ctx *ctx, int frame, int level, int r
     };
     float *Lt = get("ov.Lt"), *Lxy = get("ov.Lxy"), *Ld = get("ov.Ldet"), *kc = get("ov.kc");
     UWIP_REQUIRE(ctx, Lt && Lxy && Ld && kc, "no detect call yet");
-    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    UWIP_HIP(ctx, uwip_stream_wait(ctx));
     UWIP_REQUIRE(ctx, frame < ctx->ov_last_frames, "frame beyond the last detect batch");
     const size_t off = ((size_t)level * ctx->ov_last_frames + frame) * n;
     if (h_Lt) UWIP_HIP(ctx, hipMemcpy(h_Lt, Lt + off, n * 4, hipMemcpyDeviceToHost));
@@ -2021,7 +2021,7 @@ UWIP_API int uwip_overlap_match_ex(uwip_ctx *ctx, const uwip_features *fq, const
     int32_t *m_dist = d_match_dist ? d_match_dist : (int32_t *)uwip_ws(ctx, "ov.mdist", sizeof(int32_t) * 2 * MAXKP * (size_t)npairs);
     int32_t *info = d_info ? d_info : (int32_t *)uwip_ws(ctx, "ov.info", sizeof(int32_t) * 8 * (size_t)npairs);
     if (!h_pairs || !d_pairs || !m_idx || !m_dist || !info) return UWIP_ERR_NOMEM;
-    UWIP_HIP(ctx, hipStreamSynchronize(ctx->stream));          // pinned staging reuse
+    UWIP_HIP(ctx, uwip_stream_wait(ctx));          // pinned staging reuse
     memcpy(h_pairs, h_pair_q, sizeof(int32_t) * npairs);
     memcpy(h_pairs + npairs, h_pair_t, sizeof(int32_t) * npairs);
     UWIP_HIP(ctx, hipMemcpyAsync(d_pairs, h_pairs, sizeof(int32_t) * 2 * (size_t)npairs, hipMemcpyHostToDevice, ctx->stream));

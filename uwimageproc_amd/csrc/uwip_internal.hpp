@@ -43,6 +43,11 @@ struct uwip_ctx {
     struct pending_t { int rec; hipEvent_t a, b; };
     std::vector<pending_t> prof_pending;
     std::vector<hipEvent_t> event_pool;
+    // host waits: a blocking-sync event recorded behind the stream's work, so the calling thread SLEEPS until the stream
+    // has drained (hipStreamSynchronize spins: eight sub-batch threads of a rank burned eight cores, measured
+    // host_cpu_s_per_step 1.59 s per 0.177 s step); UWIP_CTX_SPIN_WAIT keeps the spinning wait
+    hipEvent_t wait_ev = nullptr;
+    bool spin_wait = false;
 
     int fail(int code, const char *what, const char *detail = nullptr)
     {
@@ -52,6 +57,8 @@ struct uwip_ctx {
     }
 };
 
+// Wait on the host until everything queued on the context's stream has finished (sleeping, see uwip_ctx::wait_ev).
+hipError_t uwip_stream_wait(uwip_ctx *ctx);
 void *uwip_ws(uwip_ctx *ctx, const char *name, size_t bytes);       // nullptr on failure (ctx->err set)
 void *uwip_host_ws(uwip_ctx *ctx, const char *name, size_t bytes);  // pinned host
 // Cached immutable device table: uploaded once (blocking) the first time `key` is seen.
