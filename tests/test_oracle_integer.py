@@ -422,12 +422,27 @@ def test_colour_space_known_answers(orc):
     assert np.array_equal(orc.histretch(img, "RVGY")[0], orc.histretch_ex(img, "RVGY"))
 
 
+def test_min_inliers_rule_and_the_references_four_match_rule(orc):
+    """Deviation with a switch (uwip.h UWIP_OVERLAP_MIN4): by default a homography needs >= 6 RANSAC inliers; the reference
+    takes whatever findHomography returns for >= 4 good matches (videostrip.cpp:252-272).  Four consistent matches + one
+    outlier: none by default, a homography with 4 inliers under the reference's rule."""
+    rng = np.random.default_rng(1)
+    ox = rng.uniform(50, 600, 5).astype(np.float32); oy = rng.uniform(50, 300, 5).astype(np.float32)
+    sx, sy = ox + 10, oy - 5
+    sx[4] += 80
+    assert orc.find_homography(ox, oy, sx, sy, 640, 360, seed=1)[0] == 0
+    n, H = orc.find_homography(ox, oy, sx, sy, 640, 360, seed=1, min_inliers=4)
+    assert n == 4 and np.abs(H - np.array([[1, 0, 10], [0, 1, -5], [0, 0, 1]])).max() < 1e-6
+    assert orc.find_homography(ox[:3], oy[:3], sx[:3], sy[:3], 640, 360, seed=1, min_inliers=4)[0] == 0      # < 4 matches: -2.0 either way
+
+
 # ------------------------------------------------- V1/V2: rotation and zoom ----
 @pytest.mark.parametrize("theta,scale,upright,ok", [(1.0, 1.01, False, True), (30.0, 1.0, False, True), (180.0, 1.0, False, True),
-                                                    (45.0, 1.25, False, True), (0.0, 0.8, False, True), (45.0, 1.0, True, False)])
+                                                    (45.0, 1.25, False, True), (0.0, 0.8, False, True), (45.0, 1.0, True, False),
+                                                    (0.0, 0.5, False, True), (0.0, 2.0, False, True), (20.0, 1.5, False, True)])
 def test_overlap_oracle_under_rotation_and_zoom(orc, theta, scale, upright, ok):
     """The overlap design (oracle = specification) against the TRUE homography of a synthetic camera motion (SURVEY 8d:
-    translation + rotation + scale): the ratio is within the stated +-0.01 over the full circle and zoom 0.8 ... 1.25 with the
+    translation + rotation + scale): the ratio is within the stated +-0.01 over the full circle and zoom 0.5 ... 2.0 with the
     oriented descriptor; the upright variant (SURF's `upright`) loses it at 45 degrees -- the reference's SURF is oriented
     (videostrip.cpp:206-208)."""
     key, cur, H = synth.uw_motion_pair(720, 1280, theta, scale)

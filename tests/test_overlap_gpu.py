@@ -130,12 +130,15 @@ def test_calcOverlap_end_to_end_and_known_translation(ctx, orc, stream):
 
 
 @pytest.mark.parametrize("theta,scale", [(0.5, 1.0), (1.0, 1.01), (-1.0, 0.99), (5.0, 1.0), (20.0, 0.9), (45.0, 1.0), (90.0, 1.0),
-                                         (180.0, 1.0), (-135.0, 1.1), (0.0, 0.8), (0.0, 1.25), (45.0, 1.25)])
+                                         (180.0, 1.0), (-135.0, 1.1), (0.0, 0.8), (0.0, 1.25), (45.0, 1.25),
+                                         # round 4 (profiles/r04_overlap_envelope.txt): the zoom range of an altitude change
+                                         (0.0, 0.5), (0.0, 0.67), (0.0, 1.5), (0.0, 2.0), (20.0, 0.67), (20.0, 1.5), (20.0, 2.0)])
 def test_overlap_under_rotation_and_zoom(ctx, orc, theta, scale):
     """consecutive frames are related by translation + rotation + scale.  The reference's detector is
     oriented, multi-scale SURF (videostrip.cpp:206-208); the replacement must find the same overlap when the ROV yaws or
     changes altitude.  For a camera motion with a known homography: device == oracle (1e-6), and both within the stated
-    +-0.01 of the TRUE homography pushed through the same overlapArea -- over the full circle and zoom 0.8 ... 1.25."""
+    +-0.01 of the TRUE homography pushed through the same overlapArea -- over the full circle and zoom 0.5 ... 2.0 (the four
+    levels sigma = 1.6 ... 4.5 of the one octave bridge a factor of two either way, with 20-47 inliers at the ends)."""
     vs.videoWidth, vs.videoHeight = 640, 480
     key, cur, H = synth.uw_motion_pair(1080, 1920, theta, scale)
     truth, _ = orc.overlapArea(synth.to_working_homography(H, 1920), 640, 480)
@@ -144,7 +147,7 @@ def test_overlap_under_rotation_and_zoom(ctx, orc, theta, scale):
     er, info, Hest = orc.calcOverlap(key, cur, 640, 480, seed=1)
     assert abs(r - er) <= 1e-6
     assert abs(r - truth) <= 0.01, (theta, scale, r, truth, info)
-    assert info[3] >= 40                      # inliers: a comfortable margin, not a lucky fit
+    assert info[3] >= (40 if 0.6 < scale < 1.6 else 18)       # inliers: a margin, not a lucky fit (20-47 at x0.5 / x2)
 
 
 def test_bench_stream_consecutive_frames_vs_truth(ctx, orc):

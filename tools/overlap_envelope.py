@@ -16,7 +16,9 @@ upright = "--upright" in sys.argv
 print("descriptor:", "upright (round 2)" if upright else "oriented")
 print(f"{'theta':>6} {'scale':>6} | {'ratio':>8} {'truth':>8} {'err':>7} | kp_cur kp_key good inl | verdict")
 for theta, scale in [(0, 1), (0.5, 1), (1, 1.01), (2, 1), (5, 1), (10, 1), (15, 1), (20, 1), (30, 1), (45, 1), (90, 1), (180, 1),
-                     (0, 0.8), (0, 0.9), (0, 1.1), (0, 1.25), (10, 1.1), (20, 0.9), (45, 1.25)]:
+                     (0, 0.8), (0, 0.9), (0, 1.1), (0, 1.25), (10, 1.1), (20, 0.9), (45, 1.25),
+                     # the reference's SURF spans four octaves -- chart the zoom range an altitude change covers
+                     (0, 0.5), (0, 0.67), (0, 1.5), (0, 2.0), (20, 0.5), (20, 0.67), (20, 1.5), (20, 2.0)]:
     key, cur, H = synth.uw_motion_pair(rows, cols, theta, scale)
     Hw = synth.to_working_homography(H, cols)
     truth, _ = orc.overlapArea(Hw, 640, 480)
