@@ -78,10 +78,12 @@ int uwip_ctx_create(int device, void *stream, uwip_ctx **out);
  * the calling thread (hipSetDevice) before it allocates, copies or launches. */
 #define UWIP_CTX_STREAM_GIVEN 1u
 /* Host waits.  Wherever the library waits on the host for its stream (uwip_sync, the ACLAHE parameter choice, staging
- * reuse) the calling thread SLEEPS on a blocking-sync event by default: hipStreamSynchronize spins, and a rank with
- * eight sub-batch threads then burns eight cores doing nothing (measured: 1.59 CPU-seconds per 0.177 s step), which a
- * node's CPU quota does not have for eight ranks.  UWIP_CTX_SPIN_WAIT (or the environment variable UWIP_SPIN_WAIT=1)
- * keeps the spinning wait: a few tens of microseconds less wake-up latency per wait for one core per waiting thread. */
+ * reuse, the copier's lanes) the calling thread polls an event with sleeps in between (20 ... 200 us) by default:
+ * hipStreamSynchronize and hipEventSynchronize spin on this runtime -- also on hipEventBlockingSync events; only the
+ * process-wide hipDeviceScheduleBlockingSync device flag makes them sleep, which is the host application's to set --
+ * and a rank with eight sub-batch threads then burns eight cores doing nothing (measured: 1.59 CPU-seconds per 0.177 s
+ * step), which a node's CPU quota does not have for eight ranks.  UWIP_CTX_SPIN_WAIT (or the environment variable
+ * UWIP_SPIN_WAIT=1) keeps the spinning wait: up to 200 us less wake-up latency per wait for one core per waiting thread. */
 #define UWIP_CTX_SPIN_WAIT 2u
 int uwip_ctx_create_ex(int device, void *stream, unsigned flags, uwip_ctx **out);
 int uwip_ctx_destroy(uwip_ctx *ctx);

@@ -78,14 +78,15 @@ struct uwip_copier {
                 L.q.erase(L.q.begin() + (std::ptrdiff_t)pick);
             }
             if (r.after && !ready) {
-                e = hipEventSynchronize(r.after);
+                e = uwip_event_wait(r.after, 100);
                 if (e != hipSuccess) fail("hipEventSynchronize (copy dependency)", e);
             }
             if (!failed.load()) {
                 e = hipMemcpyAsync(r.dst, r.src, r.bytes, L.kind, L.stream);
-                // sleep until the DMA engine is done (hipStreamSynchronize spins for the 7 ms of a 400 MB copy)
+                // sleep-poll until the DMA engine is done (hipStreamSynchronize spins for the 7 ms of a 400 MB copy); 50 us
+                // steps: the next copy of this direction starts when this one is seen complete
                 if (e == hipSuccess) e = hipEventRecord(L.done_ev, L.stream);
-                if (e == hipSuccess) e = hipEventSynchronize(L.done_ev);
+                if (e == hipSuccess) e = uwip_event_wait(L.done_ev, 50);
                 if (e != hipSuccess) fail(L.kind == hipMemcpyHostToDevice ? "upload" : "download", e);
             }
             {
@@ -118,8 +119,8 @@ static int submit(uwip_copier *c, int which, uwip_ctx *after, void *dst, const v
             std::lock_guard<std::mutex> lk(L.mu);
             if (!L.free_events.empty()) { ev = L.free_events.back(); L.free_events.pop_back(); }
         }
-        // blocking-sync: the lane thread sleeps on the dependency instead of spinning
-        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) return UWIP_ERR_HIP;
+        // the lane thread sleep-polls the dependency (uwip_event_wait) instead of spinning in hipEventSynchronize
+        if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return UWIP_ERR_HIP;
         hipError_t e = hipEventRecord(ev, after->stream);
         if (e != hipSuccess) { (void)hipEventDestroy(ev); return after->fail(UWIP_ERR_HIP, "hipEventRecord (copier)", hipGetErrorString(e)); }
     }
@@ -151,7 +152,7 @@ UWIP_API int uwip_copier_create(int device, uwip_copier **out)
     c->lane[1].kind = hipMemcpyDeviceToHost;
     for (auto &L : c->lane)
         if (hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&L.done_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) {
+            hipEventCreateWithFlags(&L.done_ev, hipEventDisableTiming) != hipSuccess) {
             for (auto &M : c->lane) { if (M.stream) (void)hipStreamDestroy(M.stream); if (M.done_ev) (void)hipEventDestroy(M.done_ev); }
             delete c;
             return UWIP_ERR_HIP;

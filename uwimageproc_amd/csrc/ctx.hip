@@ -2,6 +2,8 @@
 #include "uwip_internal.hpp"
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <ctime>
 
 UWIP_API const char *uwip_version(void) { return "uwip-mi355x 0.1 (gfx950)"; }
 
@@ -29,17 +31,44 @@ void uwip_trace_range(const uwip_ctx *ctx, const char *kind, const char *name, c
                  ctx ? (const void *)ctx->stream : nullptr, kind, name, p, (const void *)((const char *)p + bytes), bytes);
 }
 
+// Wait for an event WITHOUT burning a core.  Measured on this runtime (tools/ubench/wait_cpu.hip, ROCm 7.2): for a 100 ms
+// kernel hipStreamSynchronize and hipEventSynchronize cost 100 ms of thread CPU each -- also on an event created with
+// hipEventBlockingSync, which is ignored; only the process-wide hipSetDeviceFlags(hipDeviceScheduleBlockingSync) makes them
+// sleep (0.9 ms CPU), and a library has no business changing its host's device flags.  So: poll hipEventQuery, a short
+// spin first (a wait that is nearly over costs nothing extra), then nanosleep with a doubling interval up to
+// `max_sleep_us` (0.6 ms of CPU per 100 ms at 200 us).
+hipError_t uwip_event_wait(hipEvent_t ev, int max_sleep_us)
+{
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {                                            // ~30 us of polling
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        if ((t.tv_sec - t0.tv_sec) * 1000000000ll + (t.tv_nsec - t0.tv_nsec) > 30000) break;
+    }
+    long ns = 20000;
+    for (;;) {
+        timespec ts{0, ns};
+        nanosleep(&ts, nullptr);
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        ns = std::min<long>(ns * 2, (long)max_sleep_us * 1000);
+    }
+}
+
 hipError_t uwip_stream_wait(uwip_ctx *ctx)
 {
     static const bool env_spin = [] { const char *e = std::getenv("UWIP_SPIN_WAIT"); return e && *e && *e != '0'; }();
     if (ctx->spin_wait || env_spin) return hipStreamSynchronize(ctx->stream);
     if (!ctx->wait_ev) {
-        hipError_t e = hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming | hipEventBlockingSync);
+        hipError_t e = hipEventCreateWithFlags(&ctx->wait_ev, hipEventDisableTiming);
         if (e != hipSuccess) { ctx->wait_ev = nullptr; return e; }
     }
     hipError_t e = hipEventRecord(ctx->wait_ev, ctx->stream);
     if (e != hipSuccess) return e;
-    return hipEventSynchronize(ctx->wait_ev);
+    return uwip_event_wait(ctx->wait_ev, 200);
 }
 
 UWIP_API int uwip_ctx_create_ex(int device, void *stream, unsigned flags, uwip_ctx **out)

@@ -1111,6 +1111,181 @@ __global__ __launch_bounds__(64 * NW) void k_ov_match(const int8_t *__restrict__
         }
 }
 
+// The same matcher, software-pipelined (round 4).  What the ISA of the form above shows (llvm-objdump): (i) the four
+// `tpop` loads of a tile sit behind four lane-mask branches, each followed by `s_waitcnt vmcnt(0)` -- four serialised
+// global-memory round trips per 64 MFMAs; (ii) the whole top-2 epilogue of a tile (112 vector instructions) runs AFTER its
+// 64 MFMAs, right before the barrier, so all eight waves of the block alternate between a matrix phase and a vector
+// phase in step; (iii) the B fragments are read two at a time and waited for at once.  Here:
+//   * the train keys ((|b| + 512) << 11 | t, or the dead-column key) travel with the tile: fetched by 64 threads a
+//     tile ahead, parked in LDS beside the descriptors, read back with one ds_read_b32 per 16 columns;
+//   * the B fragments of column group tt + 1 are requested before the MFMAs of group tt (two register sets);
+//   * the epilogue of group tt - 1 (the last group's: of the previous tile) is issued between the MFMAs of group tt
+//     -- an MFMA holds the SIMD's vector issue for 8 of its 16 cycles, two vector instructions fit in the rest
+//     (MI355X_MICROARCH.md, "vector-instruction ISSUE cost") -- pinned with sched_group_barrier.
+// Same results bit for bit (packed-key top-2 is order-independent).
+template <int QT, int NW, int PIN>
+__global__ __launch_bounds__(64 * NW) void k_ov_match_sp(const int8_t *__restrict__ qbits, const int32_t *__restrict__ qpop,
+                                                    const int32_t *__restrict__ qn, const int8_t *__restrict__ tbits,
+                                                    const int32_t *__restrict__ tpop, const int32_t *__restrict__ tn,
+                                                    const int32_t *__restrict__ pair_q, const int32_t *__restrict__ pair_t,
+                                                    int32_t *__restrict__ out_idx /*[P][MAXKP][2]*/, int32_t *__restrict__ out_dist)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t s_t[];      // 2 x [64][MT_ROW] descriptors, then 2 x [64] keys
+    const int p = blockIdx.y;
+    const int fq = pair_q[p], ft = pair_t[p];
+    const int nq = qn[fq], nt = tn[ft];
+    const int q0 = blockIdx.x * (16 * NW * QT);
+    if (q0 >= nq) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 15, kb = lane >> 4;
+    const int8_t *Q = qbits + (size_t)fq * MAXKP * DESC_K;
+    const int8_t *T = tbits + (size_t)ft * MAXKP * DESC_K;
+    const int32_t *TP = tpop + (size_t)ft * MAXKP;
+    v4i a[QT][8];
+    int cq[QT][4];
+    uint32_t b0[QT][4], b1[QT][4];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        const int qrow = q0 + (wave * QT + u) * 16 + row;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            a[u][ks] = *reinterpret_cast<const v4i *>(Q + (size_t)qrow * DESC_K + ks * 64 + kb * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cq[u][r] = qpop[(size_t)fq * MAXKP + q0 + (wave * QT + u) * 16 + kb * 4 + r];
+            b0[u][r] = b1[u][r] = MT_EMPTY;
+        }
+    }
+    constexpr int NP = 2048 / (64 * NW);      // 16-byte pieces per thread
+    constexpr uint32_t DEAD = 0x7ff00000u;
+    v4i stage[NP];
+    uint32_t stage_key = DEAD;
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = threadIdx.x + 64 * NW * j, tr = i >> 5, piece = i & 31;
+            stage[j] = *reinterpret_cast<const v4i *>(T + (size_t)(t0 + tr) * DESC_K + piece * 16);
+        }
+        // the tile's 64 train keys (rows up to MAXKP exist; dead ones get the dead key): every wave loads and parks the
+        // same 64 values -- no branch, so the loop body stays ONE basic block and the scheduler may interleave it
+        const int t = t0 + lane;
+        const uint32_t pc = (uint32_t)TP[min(t, MAXKP - 1)];
+        // live keys are < 0x200800; a dead column ORs the dead key in (any key >= DEAD is dead).  Written as an OR, not
+        // as a select between the two keys: a select whose one arm comes from a load is turned into a branch around the
+        // load, with a vmcnt(0) wait inside it
+        stage_key = (((pc + 512u) << 11) | (uint32_t)t) | (t < nt ? 0u : DEAD);
+    };
+    int8_t *const bufA = s_t, *const bufB = s_t + (size_t)64 * MT_ROW;
+    uint32_t *const keyA = reinterpret_cast<uint32_t *>(s_t + (size_t)2 * 64 * MT_ROW), *const keyB = keyA + 64;
+    auto park = [&](int8_t *buf, uint32_t *kbuf) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = threadIdx.x + 64 * NW * j, tr = i >> 5, piece = i & 31;
+            *reinterpret_cast<v4i *>(buf + (size_t)tr * MT_ROW + piece * 16) = stage[j];
+        }
+        kbuf[lane] = stage_key;
+    };
+    if (nt > 0) {
+        fetch(0);
+        park(bufA, keyA);
+        fetch(64);                            // MAXKP >= 128: the rows exist; keys past nt are dead
+    }
+    __syncthreads();
+    // Two accumulator sets: group tt multiplies into acc[tt & 1] while the results of group tt - 1 in acc[(tt + 1) & 1] (for
+    // tt = 0: the previous tile's last group) go through the top-2 insertion.  Four groups per tile, so the parity carries
+    // over the tile loop without a register copy.
+    v4i acc[2][QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) acc[1][u] = v4i{0, 0, 0, 0};
+    uint32_t tb_last = DEAD;                  // key of the pending group of the previous tile (none yet: dead)
+    auto epilogue_one = [&](const v4i (&ac)[QT], uint32_t tbk, int idx) {
+        const int u = idx >> 2, r = idx & 3;
+        const int mf = tbk >= DEAD ? 0 : -4096;
+        top2_push(b0[u][r], b1[u][r], (uint32_t)(__mul24(ac[u][r], mf) + (int)tbk));
+    };
+    for (int t0 = 0, it = 0; t0 < nt; t0 += 64, ++it) {
+        const int8_t *cur = (it & 1) ? bufB : bufA;
+        const uint32_t *kcur = (it & 1) ? keyB : keyA;
+        uint32_t tb[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) tb[tt] = kcur[tt * 16 + row];
+        v4i bf[2][8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+            bf[0][ks] = *reinterpret_cast<const v4i *>(cur + (size_t)row * MT_ROW + ks * 64 + kb * 16);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            if (tt < 3) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    bf[(tt + 1) & 1][ks] = *reinterpret_cast<const v4i *>(cur + (size_t)((tt + 1) * 16 + row) * MT_ROW + ks * 64 + kb * 16);
+            }
+            const uint32_t tbk = tt == 0 ? tb_last : tb[(tt + 3) & 3];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) acc[tt & 1][u] = v4i{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                for (int u = 0; u < QT; ++u)
+                    acc[tt & 1][u] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[u][ks], bf[tt & 1][ks], acc[tt & 1][u], 0, 0, 0);
+                // QT * 4 pending results over the 8 steps
+                if (QT * 4 >= 8) {
+#pragma unroll
+                    for (int e = 0; e < QT * 4 / 8; ++e) epilogue_one(acc[(tt + 1) & 1], tbk, ks * (QT * 4 / 8) + e);
+                } else if ((ks & 1) == 0) {
+                    epilogue_one(acc[(tt + 1) & 1], tbk, ks >> 1);
+                }
+            }
+            // pin the order: first all eight B fragments of the NEXT group (they return under this group's 16 MFMAs),
+            // then per MFMA pair the vector work of one pending result
+            if (PIN == 1) {
+                if (tt < 3) __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // DS reads
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);      // VALU
+                }
+            } else if (PIN == 2) {
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    if (tt < 3) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);      // VALU
+                }
+            }
+        }
+        tb_last = tb[3];
+        // unconditional (clamped) staging of the next tiles: a branch here would split the body and let the compiler sink
+        // the epilogue behind it; the last two tiles park / fetch rows nobody reads
+        park((it & 1) ? bufA : bufB, (it & 1) ? keyA : keyB);
+        fetch(min(t0 + 128, MAXKP - 64));
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < QT * 4; ++i) epilogue_one(acc[1], tb_last, i);
+#pragma unroll
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const uint32_t o0 = (uint32_t)__shfl_xor((int)b0[u][r], d, 64), o1 = (uint32_t)__shfl_xor((int)b1[u][r], d, 64);
+                top2_push(b0[u][r], b1[u][r], o0);
+                top2_push(b0[u][r], b1[u][r], o1);
+            }
+            const int q = q0 + (wave * QT + u) * 16 + kb * 4 + r;
+            if (row == 0 && q < nq) {
+                const size_t o = ((size_t)p * MAXKP + q) * 2;
+                const bool h0 = b0[u][r] < DEAD, h1 = b1[u][r] < DEAD;
+                out_idx[o] = h0 ? (int)(b0[u][r] & 2047u) : -1; out_idx[o + 1] = h1 ? (int)(b1[u][r] & 2047u) : -1;
+                out_dist[o] = h0 ? (int)(b0[u][r] >> 11) - 512 + cq[u][r] : -1;
+                out_dist[o + 1] = h1 ? (int)(b1[u][r] >> 11) - 512 + cq[u][r] : -1;
+            }
+        }
+}
+
 // ---- ratio test + RANSAC homography + overlapArea, one block per pair ---------------------------------------
 __device__ __forceinline__ uint32_t hash32(uint32_t a)
 {
@@ -2027,13 +2202,27 @@ UWIP_API int uwip_overlap_match_ex(uwip_ctx *ctx, const uwip_features *fq, const
     UWIP_HIP(ctx, hipMemcpyAsync(d_pairs, h_pairs, sizeof(int32_t) * 2 * (size_t)npairs, hipMemcpyHostToDevice, ctx->stream));
     {
         uwip_kscope ks(ctx, "k_ov_match");
-        const size_t lds = (size_t)2 * 64 * MT_ROW;
-        constexpr int QT = 2;            // 2 tiles x 8 waves = 256 queries per block
-        constexpr int NW = 8;
-        int rc_l = uwip_lds_optin(ctx, "k_ov_match", (const void *)k_ov_match<QT, NW>, lds);      // 66 KB > the 64 KB default
-        if (rc_l) return rc_l;
-        k_ov_match<QT, NW><<<dim3(MAXKP / (16 * NW * QT), npairs), 64 * NW, lds, ctx->stream>>>(fq->d_bits, fq->d_pop, fq->d_n, ft->d_bits, ft->d_pop, ft->d_n,
-                                                                                    d_pairs, d_pairs + npairs, m_idx, m_dist);
+        constexpr int QT = 2;            // 2 query tiles of 16 per wave
+        static const int form = [] { const char *e = std::getenv("UWIP_MATCH_FORM"); return e && *e ? std::atoi(e) : 1; }();
+#define UWIP_LAUNCH_MATCH(KERNEL, NWV, LDSB)                                                                                   \
+        do {                                                                                                                   \
+            int rc_l = uwip_lds_optin(ctx, #KERNEL, (const void *)KERNEL, (LDSB));                                             \
+            if (rc_l) return rc_l;                                                                                             \
+            KERNEL<<<dim3(MAXKP / (16 * (NWV) * QT), npairs), 64 * (NWV), (LDSB), ctx->stream>>>(fq->d_bits, fq->d_pop, fq->d_n, ft->d_bits, \
+                                                                                         ft->d_pop, ft->d_n, d_pairs, d_pairs + npairs, m_idx, m_dist); \
+        } while (0)
+        const size_t lds0 = (size_t)2 * 64 * MT_ROW, lds1 = lds0 + 2 * 64 * sizeof(uint32_t);
+        switch (form) {                  // variants kept for A/B (tools/matcher_only.py): 0 = the round 2-3 kernel
+        case 0: UWIP_LAUNCH_MATCH((k_ov_match<QT, 8>), 8, lds0); break;
+        case 3: UWIP_LAUNCH_MATCH((k_ov_match<QT, 4>), 4, lds0); break;
+        case 2: UWIP_LAUNCH_MATCH((k_ov_match_sp<QT, 4, 0>), 4, lds1); break;
+        case 4: UWIP_LAUNCH_MATCH((k_ov_match_sp<QT, 8, 1>), 8, lds1); break;
+        case 5: UWIP_LAUNCH_MATCH((k_ov_match_sp<QT, 4, 1>), 4, lds1); break;
+        case 6: UWIP_LAUNCH_MATCH((k_ov_match_sp<QT, 8, 2>), 8, lds1); break;
+        case 7: UWIP_LAUNCH_MATCH((k_ov_match_sp<QT, 4, 2>), 4, lds1); break;
+        default: UWIP_LAUNCH_MATCH((k_ov_match_sp<QT, 8, 0>), 8, lds1); break;
+        }
+#undef UWIP_LAUNCH_MATCH
         UWIP_HIP(ctx, hipGetLastError());
     }
     {

@@ -43,9 +43,10 @@ struct uwip_ctx {
     struct pending_t { int rec; hipEvent_t a, b; };
     std::vector<pending_t> prof_pending;
     std::vector<hipEvent_t> event_pool;
-    // host waits: a blocking-sync event recorded behind the stream's work, so the calling thread SLEEPS until the stream
-    // has drained (hipStreamSynchronize spins: eight sub-batch threads of a rank burned eight cores, measured
-    // host_cpu_s_per_step 1.59 s per 0.177 s step); UWIP_CTX_SPIN_WAIT keeps the spinning wait
+    // host waits: an event recorded behind the stream's work and polled with sleeps in between, so the calling thread
+    // does not burn a core until the stream has drained (hipStreamSynchronize / hipEventSynchronize spin on this runtime,
+    // blocking-sync events included: eight sub-batch threads of a rank burned eight cores, measured host_cpu_s_per_step
+    // 1.59 s per 0.177 s step); UWIP_CTX_SPIN_WAIT keeps the spinning wait
     hipEvent_t wait_ev = nullptr;
     bool spin_wait = false;
 
@@ -59,6 +60,7 @@ struct uwip_ctx {
 
 // Wait on the host until everything queued on the context's stream has finished (sleeping, see uwip_ctx::wait_ev).
 hipError_t uwip_stream_wait(uwip_ctx *ctx);
+hipError_t uwip_event_wait(hipEvent_t ev, int max_sleep_us);      // hipEventQuery + nanosleep back-off (ctx.hip)
 void *uwip_ws(uwip_ctx *ctx, const char *name, size_t bytes);       // nullptr on failure (ctx->err set)
 void *uwip_host_ws(uwip_ctx *ctx, const char *name, size_t bytes);  // pinned host
 // Cached immutable device table: uploaded once (blocking) the first time `key` is seen.
