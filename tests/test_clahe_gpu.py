@@ -49,6 +49,34 @@ def test_clahe_bit_exact(ctx, orc, shape, grid, clip, rule):
     assert np.array_equal(out, exp)
 
 
+@pytest.mark.parametrize("shape,grid", [((300, 517), (4, 4)), ((500, 100), (6, 2)), ((280, 16), (1, 1)), ((520, 70), (3, 2)),
+                                        ((1080, 1920), (16, 16)), ((1080, 1920), (32, 32)), ((2160, 3840), (32, 32)),
+                                        ((543, 961), (7, 5)), ((64, 4100), (3, 1))])
+def test_tilehist_general_slot_keyed_form(ctx, orc, shape, grid):
+    """k_clahe_tilehist<2> (round 4): tiles of >= 4096 pixels that are padded, unaligned or not a multiple of 16 wide --
+    tail units loaded ending at the tile's last in-image column (a last tile narrower than 16 in-image pixels reads its
+    left neighbour's pixels and masks them), an image exactly 16 columns wide, reflect-101 padding rows / columns, a
+    strided view at an odd address, several frames.  LUTs (i.e. the histograms) and the output bit-exact."""
+    rows, cols = shape
+    rng = np.random.default_rng(rows * 7 + cols)
+    frames = rng.integers(0, 256, (2, rows, cols), dtype=np.uint8)
+    frames[1] = _v(orc, 9, rows, cols) if cols >= 8 else frames[1]
+    c = aclahe.CLAHE(ctx, 2.5, grid)
+    t = _dev(frames)
+    luts = c.luts(t).cpu().numpy()
+    out = c.apply(t).cpu().numpy()
+    for f in range(2):
+        exp, exp_luts = orc.clahe(frames[f], 2.5, grid[0], grid[1], 0, want_luts=True)
+        assert np.array_equal(luts[f], exp_luts), f
+        assert np.array_equal(out[f], exp), f
+    if rows * cols < 1 << 20:
+        step = cols + 13
+        buf = torch.zeros(rows * step + 64, dtype=torch.uint8, device="cuda")
+        view = buf[5:5 + rows * step].view(rows, step)[:, :cols]
+        view.copy_(t[0])
+        assert np.array_equal(c.luts(view).cpu().numpy()[0], orc.clahe(frames[0], 2.5, grid[0], grid[1], 0, want_luts=True)[1])
+
+
 @pytest.mark.parametrize("kind", ["random", "constant", "two_level", "ramp"])
 def test_clahe_adversarial(ctx, orc, kind):
     src = np.ascontiguousarray(synth.adversarial(kind, 100, 140)[..., 0])

@@ -200,7 +200,18 @@ constexpr int TH_RSTRIDE = 256 + 8;
 constexpr int TH_BP_MIN = 8192;
 constexpr int TH_BP_SLOTS = 16;
 constexpr int TH_BP_WORDS = 128 * TH_BP_SLOTS;
-template <bool BP>
+// FORM 2 (round 4): the slot-keyed layout for ANY tile -- the padded 121 x 68 / 61 x 34 tiles of the 16 x 16 / 32 x 32 grids of a
+// 1080p frame, unaligned or strided images.  A tile row is read as 16-byte units starting at the tile's own first column
+// (unaligned global_load_dwordx4: the hardware splits what crosses a line); the last unit of a row that is not a multiple of
+// 16 is loaded ENDING at the tile's last in-image column and its leading bytes -- pixels of the previous unit -- add zero
+// (a per-lane mask bit shifted into the increment: no per-pixel branch); reflect-101 padding columns and rows as in the
+// replica form.  The replica form spent 90 / 112 us per 64 frames on those grids (4 pixels per load, 16 lanes per replica),
+// against 40 us of the slot-keyed form on the aligned grids.
+// Measured per 64 frames of 1080p (tools/tilehist_only.py, UWIP_TILEHIST_GENERAL=0|1): 16 x 16 grid (121 x 68 tiles) 86 -> 67 us;
+// 32 x 32 grid (61 x 34 tiles = 2074 pixels: 33 pixels per lane against an 8 KB zero + 2048-slot flush per wave, three row
+// passes of 16 rows for 34 rows) 107 -> 157 us: those stay with the replica form.
+constexpr int TH_G_MIN = 4096;            // pixels per tile from which the 8 KB zero + flush of the slot-keyed layout pays
+template <int FORM>
 __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restrict__ src,
                                                         size_t step, size_t fstride, int rows,
                                                         int cols, int gx, int tw, int th, int split,
@@ -208,6 +219,7 @@ __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restric
                                                         const int *__restrict__ frame_map,
                                                         uint32_t *__restrict__ hists, int tiles)
 {
+    constexpr bool BP = FORM != 0;
     constexpr int HWORDS = BP ? TH_BP_WORDS : TH_REP * TH_RSTRIDE;
     __shared__ __attribute__((aligned(16))) uint32_t sh[4][HWORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -233,7 +245,44 @@ __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restric
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if constexpr (BP) {
+    if constexpr (FORM == 2) {
+        struct __attribute__((packed, aligned(1))) U16 { uint32_t x, y, z, w; };      // 16 bytes at any address
+        const int n_in = xe - xs;
+        if (n_in > 0) {
+            const int nu = (n_in + 15) >> 4, CW = min(nu, 64), RW = 64 / CW;
+            const int r = lane / CW, c = lane - r * CW;
+            if (r < RW) {
+                for (int cb = c; cb < nu; cb += 64) {
+                    const int x0 = xs + cb * 16;
+                    int xl = x0;
+                    uint32_t vm = 0xffffu;                 // bit k: byte k of the unit is a pixel of this unit
+                    if (x0 + 16 > xe) { xl = xe - 16; vm = (0xffffu << (x0 - xl)) & 0xffffu; }     // host: cols >= 16
+                    const uint8_t *colp = base + xl;
+                    constexpr int U = 4;
+                    for (int j = j0 + r; j < j1; j += RW * U) {
+                        U16 w[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int jj = min(j + u * RW, j1 - 1);           // clamped: a duplicate row is loaded, not counted
+                            w[u] = *reinterpret_cast<const U16 *>(colp + (size_t)reflect101(ty * th + jj, rows) * step);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (j + u * RW >= j1) break;
+                            const uint32_t q[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const uint32_t v = (q[k] >> (8 * b)) & 255u;
+                                    atomicAdd(&my[(v >> 1) * TH_BP_SLOTS], ((vm >> (4 * k + b)) & 1u) << ((v & 1u) << 4));
+                                }
+                        }
+                    }
+                }
+            }
+        }
+    } else if constexpr (FORM == 1) {
         // fast path (host guarantees: rows 16-byte aligned, tw a multiple of 16, no padded columns): 16 pixels per lane
         // and load, the wave covers RW rows x CW 16-byte units, four such patches in flight (4 KB per wave: at 8 waves
         // per CU that is what the HBM latency needs)
@@ -298,7 +347,7 @@ __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restric
         }
     }
     // reflected padding columns [xe, xs + tw): a handful per row
-    const int npad = BP ? 0 : xs + tw - xe;
+    const int npad = FORM == 1 ? 0 : xs + tw - xe;
     if (npad > 0) {
         for (int i = lane; i < npad * (j1 - j0); i += 64) {
             const int jr = i / npad, x = xe + (i - jr * npad);
@@ -871,10 +920,13 @@ int launch_tilehist(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g,
     constexpr long long TH_BP_PART_MAX = 3ll << 17;                   // 393 216 pixels
     const bool bp = (long long)g.tw * g.th >= TH_BP_MIN && (g.tw & 15) == 0 && g.tw * g.gx == g.cols && g.tw < (1 << 17) &&
                     ((reinterpret_cast<uintptr_t>(src->data) | src->step | src->frame_stride) & 15u) == 0;
+    // FORM 2: any other tile of >= TH_G_MIN pixels in an image at least 16 columns wide (the tail unit of a row is loaded
+    // ending at the tile's last in-image column)
+    const bool bpg = !bp && (long long)g.tw * g.th >= TH_G_MIN && g.cols >= 16 && g.tw >= 16 && g.tw < (1 << 17);
     int split;
-    if (bp) {
-        split = (int)((4096 + (size_t)tiles * nf - 1) / ((size_t)tiles * nf));
-        split = std::max(1, std::min(split, (int)(((long long)g.tw * g.th) / TH_BP_MIN)));
+    if (bp || bpg) {
+        split = (int)(((bp ? 4096 : 16384) + (size_t)tiles * nf - 1) / ((size_t)tiles * nf));
+        split = std::max(1, std::min(split, (int)(((long long)g.tw * g.th) / (bp ? TH_BP_MIN : TH_G_MIN))));
         split = std::max(split, (int)(((long long)g.tw * g.th + TH_BP_PART_MAX - 1) / TH_BP_PART_MAX));
         split = std::min(split, g.th);
     } else {
@@ -886,12 +938,16 @@ int launch_tilehist(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g,
     if (split > 1) UWIP_HIP(ctx, hipMemsetAsync(d_hists, 0, sizeof(uint32_t) * 256 * (size_t)tiles * nf, ctx->stream));
     dim3 grid((unsigned)((tiles * split + 3) / 4), (unsigned)nf);
     uwip_kscope ks(ctx, "k_clahe_tilehist");
+    static const bool no_general = [] { const char *e = std::getenv("UWIP_TILEHIST_GENERAL"); return e && *e == '0'; }();    // A/B
     if (bp)
-        k_clahe_tilehist<true><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.rows, g.cols,
-                                                              g.gx, g.tw, g.th, split, rpp, d_frame_map, d_hists, tiles);
+        k_clahe_tilehist<1><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.rows, g.cols,
+                                                           g.gx, g.tw, g.th, split, rpp, d_frame_map, d_hists, tiles);
+    else if (bpg && !no_general)
+        k_clahe_tilehist<2><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.rows, g.cols,
+                                                           g.gx, g.tw, g.th, split, rpp, d_frame_map, d_hists, tiles);
     else
-        k_clahe_tilehist<false><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.rows, g.cols,
-                                                               g.gx, g.tw, g.th, split, rpp, d_frame_map, d_hists, tiles);
+        k_clahe_tilehist<0><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.rows, g.cols,
+                                                           g.gx, g.tw, g.th, split, rpp, d_frame_map, d_hists, tiles);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
