@@ -20,4 +20,14 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU S
   echo "pmc pass $i: $set"
   timeout -k 10 300 rocprofv3 --pmc $set -d gpurun_out/pmc_${tag}_$i --output-format csv -- $B > gpurun_out/pmc_${tag}_$i.log 2>&1
 done
+# 4. the matcher on BASELINE config 4's size (64 pairs x 2048 x 2048): MFMA counters in two separate --pmc passes of
+#    tools/matcher_only.py (the program directly after --), digested by tools/pmc_matcher_digest.py
+j=0
+for set in "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU" \
+           "GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM"; do
+  j=$((j+1))
+  echo "matcher pmc pass $j: $set"
+  timeout -k 10 240 rocprofv3 --pmc $set -d gpurun_out/pmcm_${tag}_$j --output-format csv -- python3 tools/matcher_only.py > gpurun_out/pmcm_${tag}_$j.log 2>&1 || true
+done
+timeout -k 10 120 python3 tools/matcher_only.py > gpurun_out/matcher_${tag}.json 2> /dev/null || true
 echo done

@@ -444,26 +444,53 @@ void spline_derivs(const double *y, int N, double *d1, double *d2)
 {
     // second derivatives M_i: M_{i-1} + 4 M_i + M_{i+1} = 6 (y_{i-1} - 2 y_i + y_{i+1}), i = 1..N-2,
     // not-a-knot: M_0 - 2 M_1 + M_2 = 0 and M_{N-3} - 2 M_{N-2} + M_{N-1} = 0.
-    std::vector<double> A((size_t)N * N, 0.0), b(N, 0.0), M(N, 0.0);
-    A[0] = 1; A[1] = -2; A[2] = 1;
-    for (int i = 1; i < N - 1; ++i) {
-        A[(size_t)i * N + i - 1] = 1; A[(size_t)i * N + i] = 4; A[(size_t)i * N + i + 1] = 1;
-        b[i] = 6.0 * (y[i - 1] - 2.0 * y[i] + y[i + 1]);
-    }
-    A[(size_t)(N - 1) * N + N - 3] = 1; A[(size_t)(N - 1) * N + N - 2] = -2; A[(size_t)(N - 1) * N + N - 1] = 1;
-    // dense Gaussian elimination with partial pivoting (N = 25)
-    for (int c = 0; c < N; ++c) {
-        int piv = c;
-        for (int r = c + 1; r < N; ++r)
-            if (std::fabs(A[(size_t)r * N + c]) > std::fabs(A[(size_t)piv * N + c])) piv = r;
-        if (piv != c) {
-            for (int k = 0; k < N; ++k) std::swap(A[(size_t)c * N + k], A[(size_t)piv * N + k]);
-            std::swap(b[c], b[piv]);
+    // Dense Gaussian elimination with partial pivoting (N = 25).  The matrix does not depend on the data, so its
+    // elimination -- pivot rows, multipliers, the upper triangle -- is done once per N and replayed on the right-hand
+    // side: the same operations on b in the same order as eliminating [A | b] every time (bit-identical), N^2 instead
+    // of N^3 work and no allocation per curve.
+    struct Elim {
+        int N = 0;
+        std::vector<double> U;          // the eliminated matrix (upper triangle used)
+        std::vector<int> piv;           // row swapped into position c
+        std::vector<double> f;          // multiplier of row r at column c: f[c * N + r]
+    };
+    static thread_local Elim cache;
+    if (cache.N != N) {
+        Elim e;
+        e.N = N;
+        std::vector<double> &A = e.U;
+        A.assign((size_t)N * N, 0.0);
+        e.piv.assign(N, 0);
+        e.f.assign((size_t)N * N, 0.0);
+        A[0] = 1; A[1] = -2; A[2] = 1;
+        for (int i = 1; i < N - 1; ++i) { A[(size_t)i * N + i - 1] = 1; A[(size_t)i * N + i] = 4; A[(size_t)i * N + i + 1] = 1; }
+        A[(size_t)(N - 1) * N + N - 3] = 1; A[(size_t)(N - 1) * N + N - 2] = -2; A[(size_t)(N - 1) * N + N - 1] = 1;
+        for (int c = 0; c < N; ++c) {
+            int piv = c;
+            for (int r = c + 1; r < N; ++r)
+                if (std::fabs(A[(size_t)r * N + c]) > std::fabs(A[(size_t)piv * N + c])) piv = r;
+            e.piv[c] = piv;
+            if (piv != c)
+                for (int k = 0; k < N; ++k) std::swap(A[(size_t)c * N + k], A[(size_t)piv * N + k]);
+            for (int r = c + 1; r < N; ++r) {
+                const double f = A[(size_t)r * N + c] / A[(size_t)c * N + c];
+                e.f[(size_t)c * N + r] = f;
+                if (f == 0.0) continue;
+                for (int k = c; k < N; ++k) A[(size_t)r * N + k] -= f * A[(size_t)c * N + k];
+            }
         }
+        cache = std::move(e);
+    }
+    const std::vector<double> &A = cache.U;
+    double b[64], M[64];
+    if (N > 64) return;
+    b[0] = 0.0; b[N - 1] = 0.0;
+    for (int i = 1; i < N - 1; ++i) b[i] = 6.0 * (y[i - 1] - 2.0 * y[i] + y[i + 1]);
+    for (int c = 0; c < N; ++c) {
+        if (cache.piv[c] != c) std::swap(b[c], b[cache.piv[c]]);
         for (int r = c + 1; r < N; ++r) {
-            const double f = A[(size_t)r * N + c] / A[(size_t)c * N + c];
+            const double f = cache.f[(size_t)c * N + r];
             if (f == 0.0) continue;
-            for (int k = c; k < N; ++k) A[(size_t)r * N + k] -= f * A[(size_t)c * N + k];
             b[r] -= f * b[c];
         }
     }
