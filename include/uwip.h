@@ -232,6 +232,15 @@ int uwip_aclahe_sweep_hist(uwip_ctx *ctx, const uwip_batch_u8 *src, int residual
  *   [frames][5].  When 2*CL lies outside the swept grid the BS choice falls
  *   back to the last swept clip limit; uwip_aclahe_auto evaluates it exactly. */
 int uwip_aclahe_knee(const float *h_xs49, const float *h_ys49, int32_t *index);
+/* The same choice made ON THE DEVICE, from the table the sweep leaves in HBM (no copy to the host, no host computation):
+ * one wavefront per (frame, block size) runs the knee stage -- the same source as uwip_aclahe_select
+ * (csrc/lm_core.hpp), the 49 samples of a curve on 49 lanes, MINPACK's summation order kept, so host and device agree
+ * bit for bit -- and one thread per frame the choice of ACLAHE.py:92-125.
+ *   d_entropy  device, [frames][5][51] (uwip_aclahe_sweep's output)
+ *   d_par      device, [frames][4] int32 = {BS, CL, need_eval, 0}; need_eval = 1 when 2 * CL lies outside the swept grid
+ *              (BS then comes from the last swept clip limit; uwip_aclahe_auto_ex evaluates such frames exactly)
+ *   d_knee     device, [frames][5] int32, may be NULL: the five knee indices (-1 where curve_fit would raise) */
+int uwip_aclahe_select_device(uwip_ctx *ctx, const float *d_entropy, int frames, int32_t *d_par, int32_t *d_knee);
 /* The persistent host pool uwip_aclahe_select spreads its frames over (one per process, created on first use):
  * its size is the CPU budget of this rank minus the calling thread, at most 16 -- budget = min(CPUs in the affinity
  * mask, cgroup CPU quota) / ranks on the node (UWIP_RANKS_ON_NODE, else the launcher's LOCAL_WORLD_SIZE, else 1);
@@ -257,6 +266,11 @@ int uwip_GaussianBlur3(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch
  *                                  block-size search (:102-112) run on GaussianBlur(img,(3,3),0) (:15), the final
  *                                  createCLAHE(CL,(BS,BS)).apply on the unfiltered image (python/main.py:19-20). */
 #define UWIP_ACLAHE_PREFILTER 1u
+/*   UWIP_ACLAHE_HOST_SELECT        the parameter choice by uwip_aclahe_select on the host (the sweep table is copied to
+ *                                  page-locked memory, the host pool fits the curves) instead of uwip_aclahe_select_device;
+ *                                  same parameters -- the two forms agree bit for bit.  Environment UWIP_ACLAHE_SELECT=host
+ *                                  selects it process-wide. */
+#define UWIP_ACLAHE_HOST_SELECT 2u
 int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst,
                         int residual_rule, unsigned flags, int32_t *h_bs, int32_t *h_cl);
 

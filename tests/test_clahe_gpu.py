@@ -325,3 +325,75 @@ def test_tilehist_16bit_slots_do_not_overflow_on_constant_4k_tiles(ctx, orc, val
     assert (luts == luts[0]).all()
     del t
     torch.cuda.empty_cache()
+
+
+def _device_select(ctx, tab_dev):
+    import ctypes as C
+    F = tab_dev.shape[0]
+    par = torch.zeros((F, 4), dtype=torch.int32, device="cuda")
+    knee = torch.zeros((F, 5), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.call("uwip_aclahe_select_device", C.c_void_p(tab_dev.data_ptr()), F, C.c_void_p(par.data_ptr()), C.c_void_p(knee.data_ptr()))
+    ctx.sync()
+    return par.cpu().numpy(), knee.cpu().numpy()
+
+
+def _host_select(tabs):
+    import ctypes as C
+    from uwimageproc_amd import _native as nat
+    tabs = np.ascontiguousarray(tabs, np.float32)
+    F = len(tabs)
+    bs, cl, knee = (C.c_int32 * F)(), (C.c_int32 * F)(), (C.c_int32 * (5 * F))()
+    assert nat.lib().uwip_aclahe_select(tabs.ctypes.data_as(C.POINTER(C.c_float)), F, bs, cl, knee) == 0
+    return np.array(list(bs)), np.array(list(cl)), np.array(list(knee)).reshape(F, 5)
+
+
+def test_device_parameter_choice_equals_reference_goldens(ctx):
+    """uwip_aclahe_select_device (one wavefront per curve, lm_core.hpp) on the tables of tests/golden/aclahe_knee.npz: the
+    knee indices the REFERENCE's own functions.py gave (19 tables incl. the curves curve_fit gives up on), CL and BS."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "aclahe_knee.npz"), allow_pickle=False)
+    tabs = np.ascontiguousarray(g["tables"], np.float32)
+    par, knee = _device_select(ctx, _dev(tabs))
+    assert np.array_equal(knee, g["idx"])
+    bs, cl, hk = _host_select(tabs)
+    assert np.array_equal(hk, knee) and np.array_equal(par[:, 0], bs) and np.array_equal(par[:, 1], cl)
+    assert np.array_equal(par[:, 2], (2 * cl > 50).astype(np.int32))
+
+
+def test_device_parameter_choice_equals_host_on_1024_tables(ctx, orc):
+    """the device form against the host form on >= 1000 tables of the kind the pipe produces -- 1024 frames
+    of the bench's motion stream and of the plain stream (270 x 480: the table does not care about the frame size), swept
+    on the device, blurred as the pipe does; all 5120 knee indices, CL, BS and the need-evaluation flag equal."""
+    F, H, W = 64, 270, 480
+    n_equal = 0
+    for k in range(16):
+        frames = synth.uw_stream_motion(k * 7, F, H, W, seed0=1234 + 97 * k) if k % 2 == 0 else synth.uw_stream(k * 64, F, H, W)
+        v = aclahe.bgr_to_v(ctx, _dev(frames))
+        if k % 4 < 2:
+            v = aclahe.GaussianBlur3(ctx, v)
+        tab = aclahe.sweep(ctx, v)                                   # [F, 5, 51] on the device
+        par, knee = _device_select(ctx, tab)
+        bs, cl, hk = _host_select(tab.cpu().numpy())
+        assert np.array_equal(hk, knee), k
+        assert np.array_equal(par[:, 0], bs) and np.array_equal(par[:, 1], cl), k
+        assert np.array_equal(par[:, 2], (2 * cl > 50).astype(np.int32))
+        n_equal += F
+    assert n_equal == 1024
+
+
+def test_aclahe_auto_device_and_host_choice_agree(ctx, orc):
+    """uwip_aclahe_auto_ex with the device choice (default) and with UWIP_ACLAHE_HOST_SELECT: same parameters, same image."""
+    import ctypes as C
+    from uwimageproc_amd import batch_of
+    frames = np.stack([_v(orc, 300 + i, 270, 480) for i in range(5)])
+    t = _dev(frames)
+    outs = []
+    for flags in (1, 1 | 2):
+        dst = torch.empty_like(t)
+        bs, cl = (C.c_int32 * 5)(), (C.c_int32 * 5)()
+        sb, db = batch_of(t), batch_of(dst)
+        ctx.call("uwip_aclahe_auto_ex", C.byref(sb), C.byref(db), 0, flags, bs, cl)
+        ctx.sync()
+        outs.append((list(zip(bs, cl)), dst.cpu().numpy()))
+    assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])

@@ -1350,6 +1350,7 @@ UWIP_API int uwip_aclahe_sweep(uwip_ctx *ctx, const uwip_batch_u8 *src, int resi
 
 int uwip_aclahe_select_internal(const float *h_entropy, int frames, int32_t *h_bs, int32_t *h_cl, int32_t *h_knee,
                                 int32_t *h_need_eval, const float *h_extra, const int32_t *h_extra_valid);
+extern "C" int uwip_aclahe_select_device(uwip_ctx *ctx, const float *d_entropy, int frames, int32_t *d_par, int32_t *d_knee);
 
 // C3 + C4 + the final apply in one call: sweep -> (host) parameter choice -> per-frame CLAHE.
 // This is the whole "aclahe" stage of the pipe.  h_bs / h_cl receive the chosen parameters.
@@ -1360,8 +1361,10 @@ UWIP_API int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const 
     if (rc) return rc;
     if (img->frames == 0) return UWIP_OK;
     UWIP_REQUIRE(ctx, !uwip_batch_empty(img), "aclahe of an empty image");
-    UWIP_REQUIRE(ctx, (flags & ~(unsigned)UWIP_ACLAHE_PREFILTER) == 0, "unknown flag");
+    UWIP_REQUIRE(ctx, (flags & ~(unsigned)(UWIP_ACLAHE_PREFILTER | UWIP_ACLAHE_HOST_SELECT)) == 0, "unknown flag");
     const int F = img->frames;
+    static const bool env_host = [] { const char *e = getenv("UWIP_ACLAHE_SELECT"); return e && (*e == 'h' || *e == 'H'); }();
+    const bool host_select = env_host || (flags & UWIP_ACLAHE_HOST_SELECT);
     // ParametrosACLAHE searches its parameters on imgfilt = GaussianBlur(img, (3,3), 0) (ACLAHE.py:15: the sweep :40-47 and
     // the block-size search :102-112 both run on it); the final createCLAHE(CL,(BS,BS)).apply takes the unfiltered image
     // (python/main.py:19-20).  The C++ driver (aclahe.cpp:152-187) sweeps the unfiltered plane: flags = 0.
@@ -1380,15 +1383,35 @@ UWIP_API int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const 
     if (!d_ent || !h_ent || !h_par) return UWIP_ERR_NOMEM;
     rc = uwip_aclahe_sweep(ctx, src, residual_rule, d_ent);
     if (rc) return rc;
-    UWIP_HIP(ctx, hipMemcpyAsync(h_ent, d_ent, sizeof(float) * 255 * F, hipMemcpyDeviceToHost, ctx->stream));
-    UWIP_HIP(ctx, uwip_stream_wait(ctx));            // host decision point (ACLAHE.py:66-129)
     int32_t *bs = h_par, *cl = h_par + F, *need = h_par + 2 * F, *valid = h_par + 3 * F;
     float *extra = (float *)(h_par + 4 * F);
     double *clip = (double *)(extra + 5 * F);
-    rc = uwip_aclahe_select_internal(h_ent, F, bs, cl, nullptr, need, nullptr, nullptr);
-    if (rc) return ctx->fail(rc, "aclahe select");
     bool any = false;
-    for (int f = 0; f < F; ++f) { valid[f] = 0; any = any || need[f]; }
+    if (!host_select) {
+        // the choice on the device (aclahe_device.hip): only {BS, CL, need} per frame come back -- the launch geometry of
+        // the final CLAHE depends on them, which is the one reason the host still waits here
+        int32_t *d_par = (int32_t *)uwip_ws(ctx, "auto.par", sizeof(int32_t) * 4 * (size_t)F);
+        int32_t *h_dpar = (int32_t *)uwip_host_ws(ctx, "auto.dpar", sizeof(int32_t) * 4 * (size_t)F);
+        if (!d_par || !h_dpar) return UWIP_ERR_NOMEM;
+        rc = uwip_aclahe_select_device(ctx, d_ent, F, d_par, nullptr);
+        if (rc) return rc;
+        UWIP_HIP(ctx, hipMemcpyAsync(h_dpar, d_par, sizeof(int32_t) * 4 * (size_t)F, hipMemcpyDeviceToHost, ctx->stream));
+        UWIP_HIP(ctx, uwip_stream_wait(ctx));
+        for (int f = 0; f < F; ++f) {
+            bs[f] = h_dpar[4 * f]; cl[f] = h_dpar[4 * f + 1]; need[f] = h_dpar[4 * f + 2]; valid[f] = 0;
+            any = any || need[f];
+        }
+        if (any) {               // the rare frames whose clip limit leaves the swept grid go through the host form below
+            UWIP_HIP(ctx, hipMemcpyAsync(h_ent, d_ent, sizeof(float) * 255 * F, hipMemcpyDeviceToHost, ctx->stream));
+            UWIP_HIP(ctx, uwip_stream_wait(ctx));
+        }
+    } else {
+        UWIP_HIP(ctx, hipMemcpyAsync(h_ent, d_ent, sizeof(float) * 255 * F, hipMemcpyDeviceToHost, ctx->stream));
+        UWIP_HIP(ctx, uwip_stream_wait(ctx));            // host decision point (ACLAHE.py:66-129)
+        rc = uwip_aclahe_select_internal(h_ent, F, bs, cl, nullptr, need, nullptr, nullptr);
+        if (rc) return ctx->fail(rc, "aclahe select");
+        for (int f = 0; f < F; ++f) { valid[f] = 0; any = any || need[f]; }
+    }
     if (any) {
         // clip limit outside the swept grid: evaluate the five block sizes at that clip limit (ACLAHE.py:102-112)
         static const int BlockSize[5] = {2, 4, 8, 16, 32};
