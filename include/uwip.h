@@ -267,9 +267,11 @@ int uwip_GaussianBlur3(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch
  *                                  createCLAHE(CL,(BS,BS)).apply on the unfiltered image (python/main.py:19-20). */
 #define UWIP_ACLAHE_PREFILTER 1u
 /*   UWIP_ACLAHE_HOST_SELECT        the parameter choice by uwip_aclahe_select on the host (the sweep table is copied to
- *                                  page-locked memory, the host pool fits the curves) instead of uwip_aclahe_select_device;
- *                                  same parameters -- the two forms agree bit for bit.  Environment UWIP_ACLAHE_SELECT=host
- *                                  selects it process-wide. */
+ *                                  page-locked memory, the host pool fits the curves) instead of uwip_aclahe_select_device,
+ *                                  which is the default for batches of more than 4 frames (smaller ones take the host form
+ *                                  for its latency: 0.15 ms per curve on a core against 1.3 ms on one wavefront); same
+ *                                  parameters -- the two forms agree bit for bit.  Environment UWIP_ACLAHE_SELECT=host |
+ *                                  device forces one form process-wide. */
 #define UWIP_ACLAHE_HOST_SELECT 2u
 int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst,
                         int residual_rule, unsigned flags, int32_t *h_bs, int32_t *h_cl);

@@ -383,7 +383,8 @@ def test_device_parameter_choice_equals_host_on_1024_tables(ctx, orc):
 
 
 def test_aclahe_auto_device_and_host_choice_agree(ctx, orc):
-    """uwip_aclahe_auto_ex with the device choice (default) and with UWIP_ACLAHE_HOST_SELECT: same parameters, same image."""
+    """uwip_aclahe_auto_ex with the device choice (the default from 5 frames up) and with UWIP_ACLAHE_HOST_SELECT: same
+    parameters, same image."""
     import ctypes as C
     from uwimageproc_amd import batch_of
     frames = np.stack([_v(orc, 300 + i, 270, 480) for i in range(5)])

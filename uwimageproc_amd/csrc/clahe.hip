@@ -1363,8 +1363,13 @@ UWIP_API int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const 
     UWIP_REQUIRE(ctx, !uwip_batch_empty(img), "aclahe of an empty image");
     UWIP_REQUIRE(ctx, (flags & ~(unsigned)(UWIP_ACLAHE_PREFILTER | UWIP_ACLAHE_HOST_SELECT)) == 0, "unknown flag");
     const int F = img->frames;
-    static const bool env_host = [] { const char *e = getenv("UWIP_ACLAHE_SELECT"); return e && (*e == 'h' || *e == 'H'); }();
-    const bool host_select = env_host || (flags & UWIP_ACLAHE_HOST_SELECT);
+    // Where the choice is made.  Default: on the device (no table copy, no host computation: 0.25 CPU-seconds per 512-frame
+    // step and rank otherwise) -- except for batches of a few frames, where latency is what matters (the paced 4K@60 stream
+    // runs one frame per call): a curve takes one wavefront 1.3 ms on the device (a serial dependent chain of float64
+    // divisions and square roots at one instruction per ~9 cycles) and a host core 0.15 ms.  UWIP_ACLAHE_SELECT=host|device
+    // or the flag force one form; both give the same parameters bit for bit.
+    static const int env_sel = [] { const char *e = getenv("UWIP_ACLAHE_SELECT"); return !e ? 0 : ((*e == 'h' || *e == 'H') ? 1 : ((*e == 'd' || *e == 'D') ? 2 : 0)); }();
+    const bool host_select = (flags & UWIP_ACLAHE_HOST_SELECT) || env_sel == 1 || (env_sel == 0 && F <= 4);
     // ParametrosACLAHE searches its parameters on imgfilt = GaussianBlur(img, (3,3), 0) (ACLAHE.py:15: the sweep :40-47 and
     // the block-size search :102-112 both run on it); the final createCLAHE(CL,(BS,BS)).apply takes the unfiltered image
     // (python/main.py:19-20).  The C++ driver (aclahe.cpp:152-187) sweeps the unfiltered plane: flags = 0.

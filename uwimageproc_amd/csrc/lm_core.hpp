@@ -268,22 +268,42 @@ template <class B> LM_HD inline double enorm_m(const typename B::vec &x, int fro
     return x3max * sqrt(s3);
 }
 
+// 4-element arrays indexed by a run-time permutation entry: select chains, so that (with the n-loops unrolled) every
+// array of the parameter-space code lives in registers on the device -- a run-time index sends it to scratch memory, and
+// the solver is one long dependent chain through those loads (the first device build spent 2.25 ms per curve there)
+LM_HD inline double get4(const double *a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3])); }
+LM_HD inline int geti4(const int *a, int i) { return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3])); }
+LM_HD inline void seti4(int *a, int i, int x)
+{
+    a[0] = i == 0 ? x : a[0]; a[1] = i == 1 ? x : a[1]; a[2] = i == 2 ? x : a[2]; a[3] = i == 3 ? x : a[3];
+}
+LM_HD inline void set4(double *a, int i, double x)
+{
+    a[0] = i == 0 ? x : a[0]; a[1] = i == 1 ? x : a[1]; a[2] = i == 2 ? x : a[2]; a[3] = i == 3 ? x : a[3];
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LM_UNROLL _Pragma("unroll")
+#else
+#define LM_UNROLL
+#endif
+
 // ---- parameter-space solvers: MINPACK qrsolv / lmpar on the n x n triangle r (column-major, leading dimension NP) ------
 LM_HD inline void qrsolv(double *r, const int *ipvt, const double *diag, const double *qtb, double *x, double *sdiag, double *wa)
 {
     constexpr int n = NP, ldr = NP;
-    for (int j = 0; j < n; ++j) {
-        for (int i = j; i < n; ++i) r[j * ldr + i] = r[i * ldr + j];
+    LM_UNROLL for (int j = 0; j < n; ++j) {
+        LM_UNROLL for (int i = j; i < n; ++i) r[j * ldr + i] = r[i * ldr + j];
         x[j] = r[j * ldr + j];
         wa[j] = qtb[j];
     }
-    for (int j = 0; j < n; ++j) {
+    LM_UNROLL for (int j = 0; j < n; ++j) {
         const int l = ipvt[j];
-        if (diag[l] != 0.0) {
-            for (int k = j; k < n; ++k) sdiag[k] = 0.0;
-            sdiag[j] = diag[l];
+        const double diag_l = get4(diag, l);
+        if (diag_l != 0.0) {
+            LM_UNROLL for (int k = j; k < n; ++k) sdiag[k] = 0.0;
+            sdiag[j] = diag_l;
             double qtbpj = 0.0;
-            for (int k = j; k < n; ++k) {
+            LM_UNROLL for (int k = j; k < n; ++k) {
                 if (sdiag[k] == 0.0) continue;
                 double c, s;
                 const double rkk = r[k * ldr + k];
@@ -300,7 +320,7 @@ LM_HD inline void qrsolv(double *r, const int *ipvt, const double *diag, const d
                 const double temp = c * wa[k] + s * qtbpj;
                 qtbpj = -s * wa[k] + c * qtbpj;
                 wa[k] = temp;
-                for (int i = k + 1; i < n; ++i) {
+                LM_UNROLL for (int i = k + 1; i < n; ++i) {
                     const double t2 = c * r[k * ldr + i] + s * sdiag[i];
                     sdiag[i] = -s * r[k * ldr + i] + c * sdiag[i];
                     r[k * ldr + i] = t2;
@@ -311,17 +331,17 @@ LM_HD inline void qrsolv(double *r, const int *ipvt, const double *diag, const d
         r[j * ldr + j] = x[j];
     }
     int nsing = n;
-    for (int j = 0; j < n; ++j) {
+    LM_UNROLL for (int j = 0; j < n; ++j) {
         if (sdiag[j] == 0.0 && nsing == n) nsing = j;
         if (nsing < n) wa[j] = 0.0;
     }
-    for (int k = 1; k <= nsing; ++k) {
-        const int j = nsing - k;
+    LM_UNROLL for (int j = n - 1; j >= 0; --j) {          // j = nsing - 1 .. 0
+        if (j >= nsing) continue;
         double sum = 0.0;
-        for (int i = j + 1; i < nsing; ++i) sum += r[j * ldr + i] * wa[i];
+        LM_UNROLL for (int i = j + 1; i < n; ++i) if (i < nsing) sum += r[j * ldr + i] * wa[i];
         wa[j] = (wa[j] - sum) / sdiag[j];
     }
-    for (int j = 0; j < n; ++j) x[ipvt[j]] = wa[j];
+    LM_UNROLL for (int j = 0; j < n; ++j) set4(x, ipvt[j], wa[j]);
 }
 
 LM_HD inline void lmpar(double *r, const int *ipvt, const double *diag, const double *qtb, double delta, double *par, double *x,
@@ -329,41 +349,41 @@ LM_HD inline void lmpar(double *r, const int *ipvt, const double *diag, const do
 {
     constexpr int n = NP, ldr = NP;
     int nsing = n;
-    for (int j = 0; j < n; ++j) {
+    LM_UNROLL for (int j = 0; j < n; ++j) {
         wa1[j] = qtb[j];
         if (r[j * ldr + j] == 0.0 && nsing == n) nsing = j;
         if (nsing < n) wa1[j] = 0.0;
     }
-    for (int k = 1; k <= nsing; ++k) {
-        const int j = nsing - k;
+    LM_UNROLL for (int j = n - 1; j >= 0; --j) {          // j = nsing - 1 .. 0
+        if (j >= nsing) continue;
         wa1[j] /= r[j * ldr + j];
         const double temp = wa1[j];
-        for (int i = 0; i < j; ++i) wa1[i] -= r[j * ldr + i] * temp;
+        LM_UNROLL for (int i = 0; i < j; ++i) wa1[i] -= r[j * ldr + i] * temp;
     }
-    for (int j = 0; j < n; ++j) x[ipvt[j]] = wa1[j];
+    LM_UNROLL for (int j = 0; j < n; ++j) set4(x, ipvt[j], wa1[j]);
     int iter = 0;
-    for (int j = 0; j < n; ++j) wa2[j] = diag[j] * x[j];
+    LM_UNROLL for (int j = 0; j < n; ++j) wa2[j] = diag[j] * x[j];
     double dxnorm = enorm_n(n, wa2);
     double fp = dxnorm - delta;
     if (fp <= 0.1 * delta) { *par = 0.0; return; }
     double parl = 0.0;
     if (nsing >= n) {
-        for (int j = 0; j < n; ++j) {
+        LM_UNROLL for (int j = 0; j < n; ++j) {
             const int l = ipvt[j];
-            wa1[j] = diag[l] * (wa2[l] / dxnorm);
+            wa1[j] = get4(diag, l) * (get4(wa2, l) / dxnorm);
         }
-        for (int j = 0; j < n; ++j) {
+        LM_UNROLL for (int j = 0; j < n; ++j) {
             double sum = 0.0;
-            for (int i = 0; i < j; ++i) sum += r[j * ldr + i] * wa1[i];
+            LM_UNROLL for (int i = 0; i < j; ++i) sum += r[j * ldr + i] * wa1[i];
             wa1[j] = (wa1[j] - sum) / r[j * ldr + j];
         }
         const double temp = enorm_n(n, wa1);
         parl = ((fp / delta) / temp) / temp;
     }
-    for (int j = 0; j < n; ++j) {
+    LM_UNROLL for (int j = 0; j < n; ++j) {
         double sum = 0.0;
-        for (int i = 0; i <= j; ++i) sum += r[j * ldr + i] * qtb[i];
-        wa1[j] = sum / diag[ipvt[j]];
+        LM_UNROLL for (int i = 0; i <= j; ++i) sum += r[j * ldr + i] * qtb[i];
+        wa1[j] = sum / get4(diag, ipvt[j]);
     }
     const double gnorm = enorm_n(n, wa1);
     double paru = gnorm / delta;
@@ -375,21 +395,21 @@ LM_HD inline void lmpar(double *r, const int *ipvt, const double *diag, const do
         ++iter;
         if (*par == 0.0) *par = fmax(DWARF, 0.001 * paru);
         double temp = sqrt(*par);
-        for (int j = 0; j < n; ++j) wa1[j] = temp * diag[j];
+        LM_UNROLL for (int j = 0; j < n; ++j) wa1[j] = temp * diag[j];
         qrsolv(r, ipvt, wa1, qtb, x, sdiag, wa2);
-        for (int j = 0; j < n; ++j) wa2[j] = diag[j] * x[j];
+        LM_UNROLL for (int j = 0; j < n; ++j) wa2[j] = diag[j] * x[j];
         dxnorm = enorm_n(n, wa2);
         temp = fp;
         fp = dxnorm - delta;
         if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) || iter == 10) break;
-        for (int j = 0; j < n; ++j) {
+        LM_UNROLL for (int j = 0; j < n; ++j) {
             const int l = ipvt[j];
-            wa1[j] = diag[l] * (wa2[l] / dxnorm);
+            wa1[j] = get4(diag, l) * (get4(wa2, l) / dxnorm);
         }
-        for (int j = 0; j < n; ++j) {
+        LM_UNROLL for (int j = 0; j < n; ++j) {
             wa1[j] /= sdiag[j];
             const double t = wa1[j];
-            for (int i = j + 1; i < n; ++i) wa1[i] -= r[j * ldr + i] * t;
+            LM_UNROLL for (int i = j + 1; i < n; ++i) wa1[i] -= r[j * ldr + i] * t;
         }
         temp = enorm_n(n, wa1);
         const double parc = ((fp / delta) / temp) / temp;
@@ -427,22 +447,23 @@ template <class B> LM_HD inline void swap_cols(typename B::vec *a, int j, int k)
 template <class B> LM_HD inline void qrfac(int m, typename B::vec *a, int *ipvt, double *rdiag, double *acnorm, double *wa)
 {
     constexpr int n = NP;
-    for (int j = 0; j < n; ++j) {
+    LM_UNROLL for (int j = 0; j < n; ++j) {
         acnorm[j] = enorm_m<B>(a[j], 0, m);
         rdiag[j] = acnorm[j];
         wa[j] = rdiag[j];
         ipvt[j] = j;
     }
-    for (int j = 0; j < n; ++j) {
+    LM_UNROLL for (int j = 0; j < n; ++j) {
         int kmax = j;
-        for (int k = j; k < n; ++k)
-            if (rdiag[k] > rdiag[kmax]) kmax = k;
+        double rmax = rdiag[j];
+        LM_UNROLL for (int k = j; k < n; ++k)
+            if (rdiag[k] > rmax) { kmax = k; rmax = rdiag[k]; }
         if (kmax != j) {
             // constant indices on the device: the column vecs live in registers
-            for (int k = 0; k < n; ++k) if (k == kmax) swap_cols<B>(a, j, k);
-            rdiag[kmax] = rdiag[j];
-            wa[kmax] = wa[j];
-            const int t = ipvt[j]; ipvt[j] = ipvt[kmax]; ipvt[kmax] = t;
+            LM_UNROLL for (int k = 0; k < n; ++k) if (k == kmax) swap_cols<B>(a, j, k);
+            set4(rdiag, kmax, rdiag[j]);
+            set4(wa, kmax, wa[j]);
+            const int t = ipvt[j]; ipvt[j] = geti4(ipvt, kmax); seti4(ipvt, kmax, t);
         }
         double ajnorm = enorm_m<B>(a[j], j, m);
         if (ajnorm != 0.0) {
@@ -451,7 +472,7 @@ template <class B> LM_HD inline void qrfac(int m, typename B::vec *a, int *ipvt,
                 if (B::active(e, j, m)) a[j].v[e] /= ajnorm;
             const double ajj = B::at(a[j], j) + 1.0;
             B::set(a[j], j, ajj);
-            for (int k = j + 1; k < n; ++k) {
+            LM_UNROLL for (int k = j + 1; k < n; ++k) {
                 const double sum = dot_from<B>(a[j], a[k], j, m);
                 const double temp = sum / ajj;
                 for (int e = B::begin(j); e < B::end(m); ++e)
@@ -490,7 +511,7 @@ template <class B> LM_HD inline int lmdif(const typename B::vec &y, int m, doubl
     const double eps = sqrt(EPSMCH);
     for (;;) {
         // forward-difference Jacobian (fdjac2)
-        for (int j = 0; j < n; ++j) {
+        LM_UNROLL for (int j = 0; j < n; ++j) {
             const double temp = x[j];
             double h = eps * fabs(temp);
             if (h == 0.0) h = eps;
@@ -502,17 +523,17 @@ template <class B> LM_HD inline int lmdif(const typename B::vec &y, int m, doubl
         nfev += n;
         qrfac<B>(m, fjac, ipvt, wa1, wa2, wa3);
         if (iter == 1) {
-            for (int j = 0; j < n; ++j) {
+            LM_UNROLL for (int j = 0; j < n; ++j) {
                 diag[j] = wa2[j];
                 if (wa2[j] == 0.0) diag[j] = 1.0;
             }
-            for (int j = 0; j < n; ++j) wa3[j] = diag[j] * x[j];
+            LM_UNROLL for (int j = 0; j < n; ++j) wa3[j] = diag[j] * x[j];
             xnorm = enorm_n(n, wa3);
             delta = factor * xnorm;
             if (delta == 0.0) delta = factor;
         }
         for (int e = B::begin(0); e < B::end(m); ++e) wa4.v[e] = fvec.v[e];
-        for (int j = 0; j < n; ++j) {
+        LM_UNROLL for (int j = 0; j < n; ++j) {
             const double fjj = B::at(fjac[j], j);
             if (fjj != 0.0) {
                 const double sum = dot_from<B>(fjac[j], wa4, j, m);
@@ -524,26 +545,26 @@ template <class B> LM_HD inline int lmdif(const typename B::vec &y, int m, doubl
             qtf[j] = B::at(wa4, j);
         }
         // the n x n upper triangle, column-major: r[j * n + i] = fjac[j][i], i <= j (lmpar overwrites its strict lower part)
-        for (int j = 0; j < n; ++j)
-            for (int i = 0; i < n; ++i) rmat[j * NP + i] = B::at(fjac[j], i);
+        LM_UNROLL for (int j = 0; j < n; ++j)
+            LM_UNROLL for (int i = 0; i < n; ++i) rmat[j * NP + i] = B::at(fjac[j], i);
         gnorm = 0.0;
         if (fnorm != 0.0) {
-            for (int j = 0; j < n; ++j) {
-                const int l = ipvt[j];
-                if (wa2[l] != 0.0) {
+            LM_UNROLL for (int j = 0; j < n; ++j) {
+                const double wa2l = get4(wa2, ipvt[j]);
+                if (wa2l != 0.0) {
                     double sum = 0.0;
-                    for (int i = 0; i <= j; ++i) sum += rmat[j * NP + i] * (qtf[i] / fnorm);
-                    gnorm = fmax(gnorm, fabs(sum / wa2[l]));
+                    LM_UNROLL for (int i = 0; i <= j; ++i) sum += rmat[j * NP + i] * (qtf[i] / fnorm);
+                    gnorm = fmax(gnorm, fabs(sum / wa2l));
                 }
             }
         }
         if (gnorm <= gtol) { info = 4; break; }
-        for (int j = 0; j < n; ++j) diag[j] = fmax(diag[j], wa2[j]);
+        LM_UNROLL for (int j = 0; j < n; ++j) diag[j] = fmax(diag[j], wa2[j]);
         double ratio = 0.0;
         do {
             double sdiag[NP], scr[NP];
             lmpar(rmat, ipvt, diag, qtf, delta, &par, wa1, sdiag, wa3, scr);
-            for (int j = 0; j < n; ++j) {
+            LM_UNROLL for (int j = 0; j < n; ++j) {
                 wa1[j] = -wa1[j];
                 wa2[j] = x[j] + wa1[j];
                 wa3[j] = diag[j] * wa1[j];
@@ -558,10 +579,10 @@ template <class B> LM_HD inline int lmdif(const typename B::vec &y, int m, doubl
                 const double t = fnorm1 / fnorm;
                 actred = 1.0 - t * t;
             }
-            for (int j = 0; j < n; ++j) {
+            LM_UNROLL for (int j = 0; j < n; ++j) {
                 wa3[j] = 0.0;
-                const double temp = wa1[ipvt[j]];
-                for (int i = 0; i <= j; ++i) wa3[i] += rmat[j * NP + i] * temp;
+                const double temp = get4(wa1, ipvt[j]);
+                LM_UNROLL for (int i = 0; i <= j; ++i) wa3[i] += rmat[j * NP + i] * temp;
             }
             const double temp1 = enorm_n(n, wa3) / fnorm;
             const double temp2 = (sqrt(par) * pnorm) / fnorm;
@@ -580,7 +601,7 @@ template <class B> LM_HD inline int lmdif(const typename B::vec &y, int m, doubl
                 par *= 0.5;
             }
             if (ratio >= 1e-4) {
-                for (int j = 0; j < n; ++j) {
+                LM_UNROLL for (int j = 0; j < n; ++j) {
                     x[j] = wa2[j];
                     wa2[j] = diag[j] * x[j];
                 }
