@@ -25,4 +25,4 @@ for g in (2, 4, 8, 16, 32):
         ctx.call("uwip_clahe", C.byref(ib), C.byref(ob), C.c_double(3.0), g, g, 0)
     ctx.sync()
     r = ctx.prof_results(); ctx.prof_enable(False)
-    print(f"grid {g:2d}: " + "  ".join(f"{k} {ms/cnt*1e3:7.1f} us" for k, (ms, cnt) in r.items()), flush=True)
+    print(f"grid {g:2d}: " + "  ".join(f"{k} {ms/cnt*1e3:7.1f} us" for k, (ms, cnt) in r.items()) + f"   whole {sum(ms/cnt for ms, cnt in r.values())*1e3:7.1f} us = {3.0*H*W*F/(sum(ms/cnt for ms, cnt in r.values())*1e-3)/8e12:.3f} of 8 TB/s", flush=True)

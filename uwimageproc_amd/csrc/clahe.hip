@@ -410,24 +410,18 @@ static __device__ const SteprTab D_STEPR = make_stepr_tab();
 // One wave per (tile, frame); lane l owns bins 4l..4l+3 and the wave walks all clip limits with shuffle-only
 // reductions and scans (no barriers).  Arithmetic is cv::CLAHE's: integer clip / redistribute, then
 // lut = sat_u8(rne(float(cumsum) * lutScale)).
-__global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ hists, int tiles, int nf,
-                                                   float lutScale, ClipList cl,
-                                                   const int *__restrict__ frame_clip, int rule,
-                                                   uint8_t *__restrict__ luts, uint32_t *__restrict__ tile_max /*optional*/)
+// the wave-level body: h0 = this lane's four bins of the tile's histogram; writes the tile's ncl LUT rows (256 B each, lane l
+// the bytes 4l .. 4l+3) from `out` on and, optionally, the tallest bin
+__device__ __forceinline__ void clahe_lut_rows(const int (&h0)[4], int lane, float lutScale, const ClipList &cl, int frame_clip /*< 0: none*/,
+                                               int rule, uint8_t *__restrict__ out, uint32_t *__restrict__ tile_max_out)
 {
-    const int lane = threadIdx.x & 63;
-    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv >= (long long)tiles * nf) return;
-    const int f = (int)(wv / tiles), t = (int)(wv - (long long)f * tiles);
-    const uint4 hv = *reinterpret_cast<const uint4 *>(hists + ((size_t)f * tiles + t) * 256 + lane * 4);
-    const int h0[4] = {(int)hv.x, (int)hv.y, (int)hv.z, (int)hv.w};
     const int ncl = cl.n;
     // the tile's tallest bin: a clip limit at or above it clips nothing (cv::CLAHE clips bins > limit only), so its LUT is
     // the unclipped one -- computed once here, and k_clahe_sweep never evaluates such limits
     int m = max(max(h0[0], h0[1]), max(h0[2], h0[3]));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d));
-    if (tile_max && lane == 0) tile_max[(size_t)f * tiles + t] = (uint32_t)m;
+    if (tile_max_out && lane == 0) *tile_max_out = (uint32_t)m;
     auto lut_word = [&](const int h[4]) {
         const int p0 = h[0], p1 = p0 + h[1], p2 = p1 + h[2], p3 = p2 + h[3];
         const int off = (int)wave_incl_scan_u32((uint32_t)p3) - p3;
@@ -439,7 +433,7 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
     };
     const uint32_t w_unclipped = lut_word(h0);
     for (int c = 0; c < ncl; ++c) {
-        const int clip = frame_clip ? frame_clip[f] : cl.clip[c];
+        const int clip = frame_clip >= 0 ? frame_clip : cl.clip[c];
         uint32_t w = w_unclipped;
         if (clip > 0 && clip < m) {                                    // wave-uniform
             int h[4] = {h0[0], h0[1], h0[2], h0[3]};
@@ -469,8 +463,115 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
             }
             w = lut_word(h);
         }
-        // [frame][tile][clip limit][256]: the wave's rows are one contiguous run (ncl = 1: the plain [frame][tile][256] table)
-        *reinterpret_cast<uint32_t *>(luts + (((size_t)f * tiles + t) * ncl + c) * 256 + lane * 4) = w;
+        *reinterpret_cast<uint32_t *>(out + (size_t)c * 256 + lane * 4) = w;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ hists, int tiles, int nf,
+                                                   float lutScale, ClipList cl,
+                                                   const int *__restrict__ frame_clip, int rule,
+                                                   uint8_t *__restrict__ luts, uint32_t *__restrict__ tile_max /*optional*/)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= (long long)tiles * nf) return;
+    const int f = (int)(wv / tiles), t = (int)(wv - (long long)f * tiles);
+    const uint4 hv = *reinterpret_cast<const uint4 *>(hists + ((size_t)f * tiles + t) * 256 + lane * 4);
+    const int h0[4] = {(int)hv.x, (int)hv.y, (int)hv.z, (int)hv.w};
+    // [frame][tile][clip limit][256]: the wave's rows are one contiguous run (ncl = 1: the plain [frame][tile][256] table)
+    clahe_lut_rows(h0, lane, lutScale, cl, frame_clip ? frame_clip[f] : -1, rule, luts + (((size_t)f * tiles + t) * cl.n) * 256,
+                   tile_max ? tile_max + (size_t)f * tiles + t : nullptr);
+}
+
+// ---- C1a + C1b fused for small or padded tiles: one block per ROW OF TILES (round 4) -------------------------------------------
+// The 61 x 34 tiles of the 32 x 32 grid of a 1080p frame (and the 121 x 68 ones of 16 x 16) are too small for a per-wave
+// histogram image (8 KB of zeroing and flushing per 2074 pixels) and not aligned to anything, which left the replica form
+// at 107 us per 64 frames against 40 us on the big aligned tiles.  Here a 512-thread block owns one row of tiles of one
+// frame: gx histograms in LDS -- two 16-bit counters per word, BAND_SLOTS lane-keyed slots per pair of bins, tiles skewed by
+// four banks -- filled from WHOLE IMAGE ROWS read as 16-byte units (a unit straddles at most two tiles: the counter base of
+// each of its 16 pixels is precomputed per lane, the units a lane owns sit in the same columns of every row), the
+// reflect-101 padding columns on a per-pixel path, padding rows by index; then the block's waves turn the histograms into
+// LUT rows themselves (clahe_lut_rows) -- the 1 KB per tile of histogram never travels to HBM and back, and there is no
+// second launch.
+constexpr int BAND_SLOTS = 4;
+constexpr int BAND_TSTRIDE = 128 * BAND_SLOTS + 4;          // words per tile: + 4 = the bank skew between neighbouring tiles
+constexpr int BAND_THREADS = 512;
+template <int CHUNKS>       // 64-unit chunks per image row (1, 2, 4, 8); BAND_THREADS / 64 / CHUNKS waves share a chunk
+__global__ __launch_bounds__(BAND_THREADS) void k_clahe_band(const uint8_t *__restrict__ src, size_t step, size_t fstride, int rows, int cols,
+                                                             int gx, int tw, uint32_t tw_magic, int th, const int *__restrict__ frame_map, float lutScale,
+                                                             ClipList cl, const int *__restrict__ frame_clip, int rule,
+                                                             uint8_t *__restrict__ luts, uint32_t *__restrict__ tile_max, int tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_band[];      // [gx][BAND_TSTRIDE]
+    struct __attribute__((packed, aligned(1))) U16 { uint32_t x, y, z, w; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ty = blockIdx.x, f = blockIdx.y;
+    const int fr = frame_map ? frame_map[f] : f;
+    const uint8_t *base = src + (size_t)fr * fstride;
+    for (int i = tid; i < gx * BAND_TSTRIDE; i += BAND_THREADS) s_band[i] = 0;
+    __syncthreads();
+    constexpr int WPC = BAND_THREADS / 64 / CHUNKS;          // waves per chunk
+    const int chunk = wave / WPC, wrow = wave - chunk * WPC;
+    const int nu = (cols + 15) >> 4;
+    const int u = chunk * 64 + lane;
+    if (u < nu) {
+        // this lane's unit: pixels [x0, x0 + 16) of every row -- the last unit of a row whose width is not a multiple of 16
+        // is loaded ENDING at the last column and its leading bytes, pixels of the previous unit, add zero
+        const int x0 = u * 16;
+        int xl = x0;
+        uint32_t vm = 0xffffu;
+        if (x0 + 16 > cols) { xl = cols - 16; vm = (0xffffu << (x0 - xl)) & 0xffffu; }
+        // LDS byte address of the counter image of the tile each of the 16 loaded pixels falls in (+ this lane's slot)
+        uint32_t cbase[16];
+        const uint32_t slot = (uint32_t)(lane & (BAND_SLOTS - 1)) * 4u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int x = xl + k;
+            const int tx = (int)__umulhi((unsigned)x, tw_magic);       // x / tw: tw_magic = floor(2^32 / tw) + 1, exact while x * tw < 2^32
+            cbase[k] = (uint32_t)tx * (BAND_TSTRIDE * 4u) + slot;
+        }
+        const uint8_t *colp = base + xl;
+        constexpr int U = 4;
+        for (int j = wrow; j < th; j += WPC * U) {
+            U16 w[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const int jj = min(j + q * WPC, th - 1);           // clamped: a duplicate row is loaded, not counted
+                w[q] = *reinterpret_cast<const U16 *>(colp + (size_t)reflect101(ty * th + jj, rows) * step);
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                if (j + q * WPC >= th) break;
+                const uint32_t d[4] = {w[q].x, w[q].y, w[q].z, w[q].w};
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t v = (d[k >> 2] >> (8 * (k & 3))) & 255u;
+                    const uint32_t inc = ((vm >> k) & 1u) << ((v & 1u) << 4);
+                    atomicAdd(reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(s_band) + cbase[k] + (v >> 1) * (BAND_SLOTS * 4u)), inc);
+                }
+            }
+        }
+    }
+    // reflected padding columns [cols, gx * tw): a few per row
+    const int npad = gx * tw - cols;
+    for (int i = tid; i < npad * th; i += BAND_THREADS) {
+        const int jr = i / npad, x = cols + (i - jr * npad);
+        const uint32_t v = base[(size_t)reflect101(ty * th + jr, rows) * step + reflect101(x, cols)];
+        const int tx = x / tw;
+        atomicAdd(&s_band[tx * BAND_TSTRIDE + (v >> 1) * BAND_SLOTS + (tid & (BAND_SLOTS - 1))], (v & 1u) ? 65536u : 1u);
+    }
+    __syncthreads();
+    // histograms -> LUT rows: a wave per tile, lane l owns bins 4l .. 4l+3 = pairs 2l, 2l + 1
+    for (int tx = wave; tx < gx; tx += BAND_THREADS / 64) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(&s_band[tx * BAND_TSTRIDE + (2 * lane) * BAND_SLOTS]);
+        const uint4 b = *reinterpret_cast<const uint4 *>(&s_band[tx * BAND_TSTRIDE + (2 * lane + 1) * BAND_SLOTS]);
+        static_assert(BAND_SLOTS == 4, "one 16-byte read per pair of bins");
+        // a tile holds < 65536 pixels (host: checked), so the packed halves can be added as whole words
+        const uint32_t sa = a.x + a.y + a.z + a.w, sb = b.x + b.y + b.z + b.w;
+        const int h0[4] = {(int)(sa & 0xffffu), (int)(sa >> 16), (int)(sb & 0xffffu), (int)(sb >> 16)};
+        const int t = ty * gx + tx;
+        clahe_lut_rows(h0, lane, lutScale, cl, frame_clip ? frame_clip[f] : -1, rule, luts + (((size_t)f * tiles + t) * cl.n) * 256,
+                       tile_max ? tile_max + (size_t)f * tiles + t : nullptr);
     }
 }
 
@@ -962,6 +1063,45 @@ int launch_lut(uwip_ctx *ctx, const ClaheGeom &g, const uint32_t *d_hists, const
     return UWIP_OK;
 }
 
+// tile histograms + LUT rows in one launch (k_clahe_band) where the geometry allows and the big-tile form does not apply
+bool band_ok(const uwip_batch_u8 *src, const ClaheGeom &g)
+{
+    static const bool off = [] { const char *e = std::getenv("UWIP_CLAHE_BAND"); return e && *e == '0'; }();      // A/B
+    const bool bp = (long long)g.tw * g.th >= TH_BP_MIN && (g.tw & 15) == 0 && g.tw * g.gx == g.cols && g.tw < (1 << 17) &&
+                    ((reinterpret_cast<uintptr_t>(src->data) | src->step | src->frame_stride) & 15u) == 0;
+    return !off && !bp && g.cols >= 16 && g.cols <= 8192 && (long long)g.tw * g.th < 65536 &&
+           (size_t)g.gx * BAND_TSTRIDE * 4 <= 96 * 1024 && g.gy <= 65535;
+}
+
+int launch_band(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g, const int *d_frame_map, int nf, const ClipList &cl,
+                const int *d_frame_clip, int rule, uint8_t *d_luts, uint32_t *d_tile_max)
+{
+    const int nu = (g.cols + 15) >> 4;
+    const int chunks = nu <= 64 ? 1 : (nu <= 128 ? 2 : (nu <= 256 ? 4 : 8));
+    const size_t lds = (size_t)g.gx * BAND_TSTRIDE * 4;
+    const uint32_t magic = (uint32_t)(4294967296ull / (uint64_t)g.tw) + 1u;
+    const int tiles = g.gx * g.gy;
+    dim3 grid((unsigned)g.gy, (unsigned)nf);
+    uwip_kscope ks(ctx, "k_clahe_band");
+#define UWIP_BAND(C)                                                                                                                   \
+    do {                                                                                                                               \
+        int rc_l = uwip_lds_optin(ctx, "k_clahe_band" #C, (const void *)k_clahe_band<C>, lds);                                          \
+        if (rc_l) return rc_l;                                                                                                         \
+        k_clahe_band<C><<<grid, BAND_THREADS, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.rows, g.cols, \
+                                                               g.gx, g.tw, magic, g.th, d_frame_map, g.lutScale, cl, d_frame_clip, rule, \
+                                                               d_luts, d_tile_max, tiles);                                              \
+    } while (0)
+    switch (chunks) {
+    case 1: UWIP_BAND(1); break;
+    case 2: UWIP_BAND(2); break;
+    case 4: UWIP_BAND(4); break;
+    default: UWIP_BAND(8); break;
+    }
+#undef UWIP_BAND
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}
+
 // strip table for (rows, gy, th, max_rows): built once per geometry and cached
 int build_strips(uwip_ctx *ctx, const ClaheGeom &g, int max_rows, const int4 **d_strips, int *nstrips)
 {
@@ -1126,13 +1266,14 @@ UWIP_API int uwip_clahe_luts(uwip_ctx *ctx, const uwip_batch_u8 *src, double cli
     UWIP_REQUIRE(ctx, d_luts != nullptr, "null LUT buffer");
     const ClaheGeom g = make_geom(src->rows, src->cols, gx, gy);
     const int tiles = gx * gy;
+    ClipList cl{};
+    cl.n = 1;
+    cl.clip[0] = clip_from_limit(clipLimit, g.area);
+    if (band_ok(src, g)) return launch_band(ctx, src, g, nullptr, src->frames, cl, nullptr, residual_rule, d_luts, nullptr);
     uint32_t *d_hists = (uint32_t *)uwip_ws(ctx, "clahe.tilehist", sizeof(uint32_t) * 256 * (size_t)tiles * src->frames);
     if (!d_hists) return UWIP_ERR_NOMEM;
     rc = launch_tilehist(ctx, src, g, nullptr, src->frames, d_hists);
     if (rc) return rc;
-    ClipList cl{};
-    cl.n = 1;
-    cl.clip[0] = clip_from_limit(clipLimit, g.area);
     return launch_lut(ctx, g, d_hists, cl, nullptr, src->frames, residual_rule, d_luts);
 }
 
@@ -1201,12 +1342,17 @@ UWIP_API int uwip_clahe_per_frame(uwip_ctx *ctx, const uwip_batch_u8 *src, const
         const int nf = j - i;
         const ClaheGeom g = make_geom(src->rows, src->cols, gsz, gsz);
         const int tiles = gsz * gsz;
-        rc = launch_tilehist(ctx, src, g, d_map + i, nf, d_hists);
-        if (rc) return rc;
         ClipList cl{};
         cl.n = 1;
-        rc = launch_lut(ctx, g, d_hists, cl, d_clip + i, nf, residual_rule, d_luts + loff);
-        if (rc) return rc;
+        if (band_ok(src, g)) {
+            rc = launch_band(ctx, src, g, d_map + i, nf, cl, d_clip + i, residual_rule, d_luts + loff, nullptr);
+            if (rc) return rc;
+        } else {
+            rc = launch_tilehist(ctx, src, g, d_map + i, nf, d_hists);
+            if (rc) return rc;
+            rc = launch_lut(ctx, g, d_hists, cl, d_clip + i, nf, residual_rule, d_luts + loff);
+            if (rc) return rc;
+        }
         // d_hists is reused by the next group: stream order keeps that safe
         const ApplyShape sh = apply_shape(g);
         const int4 *d_strips = nullptr;
@@ -1269,26 +1415,36 @@ UWIP_API int uwip_aclahe_sweep_hist(uwip_ctx *ctx, const uwip_batch_u8 *src, int
     UWIP_HIP(ctx, hipMemsetAsync(d_out, 0, sizeof(uint32_t) * out_fs * F, ctx->stream));
     // finest grid first: a coarser unpadded grid sums the tile histograms of the grid twice as fine
     ClaheGeom finer{};
+    bool finer_has_hists = false;
     for (int gi = 4; gi >= 0; --gi) {
         const int gsz = BlockSize[gi];
         const ClaheGeom g = make_geom(src->rows, src->cols, gsz, gsz);
         uint32_t *d_hists = hbuf[gi & 1];
         const bool nested = gi < 4 && finer.gx == 2 * g.gx && finer.gy == 2 * g.gy && finer.pc == finer.cols && finer.pr == finer.rows &&
                             g.pc == g.cols && g.pr == g.rows && finer.tw * 2 == g.tw && finer.th * 2 == g.th;
-        if (nested) {
-            uwip_kscope ks(ctx, "k_clahe_tilehist");
-            k_clahe_tilehist_merge<<<dim3((unsigned)(g.gx * g.gy), (unsigned)F), 256, 0, ctx->stream>>>(hbuf[(gi + 1) & 1], g.gx, g.gx * g.gy, d_hists);
-            UWIP_HIP(ctx, hipGetLastError());
-        } else {
-            rc = launch_tilehist(ctx, src, g, nullptr, F, d_hists);
-            if (rc) return rc;
-        }
-        finer = g;
         ClipList cl{};
         cl.n = 0;
         for (float c = 0.0f; c <= 25.0f; c += 0.5f) cl.clip[cl.n++] = clip_from_limit((double)c, g.area);
-        rc = launch_lut(ctx, g, d_hists, cl, nullptr, F, residual_rule, d_luts, d_tmax);
-        if (rc) return rc;
+        if (nested && finer_has_hists) {
+            uwip_kscope ks(ctx, "k_clahe_tilehist");
+            k_clahe_tilehist_merge<<<dim3((unsigned)(g.gx * g.gy), (unsigned)F), 256, 0, ctx->stream>>>(hbuf[(gi + 1) & 1], g.gx, g.gx * g.gy, d_hists);
+            UWIP_HIP(ctx, hipGetLastError());
+            finer_has_hists = true;
+        } else if (band_ok(src, g)) {
+            // histograms and the 51 LUT rows of every tile in one launch; the histograms stay in LDS
+            rc = launch_band(ctx, src, g, nullptr, F, cl, nullptr, residual_rule, d_luts, d_tmax);
+            if (rc) return rc;
+            finer_has_hists = false;
+        } else {
+            rc = launch_tilehist(ctx, src, g, nullptr, F, d_hists);
+            if (rc) return rc;
+            finer_has_hists = true;
+        }
+        finer = g;
+        if (finer_has_hists) {
+            rc = launch_lut(ctx, g, d_hists, cl, nullptr, F, residual_rule, d_luts, d_tmax);
+            if (rc) return rc;
+        }
         // work items: interpolation cells cut into row chunks of <= ~16K pixels (cached per geometry)
         char key[96];
         snprintf(key, sizeof key, "cells:%d:%d:%d", g.rows, g.cols, gsz);
