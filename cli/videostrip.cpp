@@ -35,7 +35,9 @@ int main(int argc, char **argv)
     const Args a = parse_args(argc, argv, {"k", "windowSize", "s", "timeSkip", "p", "minOverlap", "g", "gpus"});
     if (a.pos.size() < 2 || a.has("h") || a.has("help")) {
         std::printf("videostrip - smart extraction of video frames\n"
-                    "usage: videostrip [-k windowSize] [-s timeSkip] [-p minOverlap] [-r] [--png] [-g gpus] <video.avi (Motion-JPEG) | frame_list.txt> <output_prefix>\n");
+                    "usage: videostrip [-k windowSize] [-s timeSkip] [-p minOverlap] [-r] [--png] [--min4] [-g gpus] <video.avi (Motion-JPEG) | frame_list.txt> <output_prefix>\n"
+                    "  --min4  accept any homography found from >= 4 good matches, as the reference does (videostrip.cpp:252-272);\n"
+                    "          default: a homography needs >= 6 RANSAC inliers\n");
         return 0;
     }
     const int kWindow = std::atoi(a.get("k", a.get("windowSize", std::to_string(DEFAULT_KWINDOW))).c_str());
@@ -43,6 +45,7 @@ int main(int argc, char **argv)
     const double minOverlap = std::atof(a.get("p", a.get("minOverlap", std::to_string(OVERLAP_MIN))).c_str());
     const std::string InputFile = a.pos[0], OutputFile = a.pos[1];
     const char *ext = a.has("png") ? "png" : "jpg";
+    const unsigned match_flags = a.has("min4") ? UWIP_OVERLAP_MIN4 : 0u;
     std::vector<std::string> frames;
     avi::Reader video;
     const bool is_avi = imgio::ends_with(InputFile, ".avi");
@@ -148,7 +151,7 @@ int main(int argc, char **argv)
                     const int m = (int)std::min<size_t>(LOOKAHEAD, nn - nxt);
                     int32_t pq[LOOKAHEAD], pt[LOOKAHEAD];
                     for (int j = 0; j < m; ++j) { upload(1 + j, rec[nxt + j]); pq[j] = 1 + j; pt[j] = 0; }
-                    ctx.check(uwip_overlap_match(ctx.get(), fs, fs, pq, pt, m, vw, vh, 1, d_ratio, nullptr, nullptr, nullptr, nullptr));
+                    ctx.check(uwip_overlap_match_ex(ctx.get(), fs, fs, pq, pt, m, vw, vh, 1, match_flags, d_ratio, nullptr, nullptr, nullptr, nullptr));
                     ctx.check(uwip_memcpy_d2h(ctx.get(), spec, d_ratio, sizeof(float) * m));
                     spec_key = key; spec_at = nxt; spec_n = (size_t)m;
                 }
@@ -192,6 +195,7 @@ int main(int argc, char **argv)
     try {
         uw::Context ctx(0);
         uw::Videostrip vsx(ctx);
+        vsx.match_flags = match_flags;
         uw::keyframe kframe;
         imgio::Image kimg, frame, bestframe;
         uw::Mat res;                              // res_frame: cv::resize(frame, res_frame, Size(), f, f), main.cpp:311

@@ -164,6 +164,7 @@ struct keyframe {                 // videostrip.hpp:62-68 (keypoints/descriptors
 class Videostrip {
 public:
     int videoWidth = 0, videoHeight = 0;          // the reference's globals (main.cpp:45-46)
+    unsigned match_flags = 0;                     // UWIP_OVERLAP_MIN4: the reference's ">= 4 good matches" rule (videostrip.cpp:252-272)
     explicit Videostrip(Context &c) : c_(c)
     {
         c_.check(uwip_features_create(c_.get(), 1, &obj_));
@@ -186,8 +187,8 @@ public:
         DeviceMat o(c_, img_object);
         c_.check(uwip_overlap_detect(c_.get(), o.batch(), obj_, 0));
         int32_t q = 0, t = 0;
-        c_.check(uwip_overlap_match(c_.get(), obj_, kframe->feats, &q, &t, 1, videoWidth, videoHeight, seed, (float *)scratch_,
-                                    nullptr, nullptr, nullptr, nullptr));
+        c_.check(uwip_overlap_match_ex(c_.get(), obj_, kframe->feats, &q, &t, 1, videoWidth, videoHeight, seed, match_flags,
+                                       (float *)scratch_, nullptr, nullptr, nullptr, nullptr));
         float r = 0.f;
         c_.check(uwip_memcpy_d2h(c_.get(), &r, scratch_, 4));
         if (r == -2.0f) std::printf("[WARN] Not enough good matches!\n");
