@@ -296,3 +296,34 @@ def test_resize_bgr_and_selector_on_1080p(ctx, orc):
             if eof:
                 break
     assert [(a, b) for a, b, _, _ in got] == exp and len(exp) >= 2, (got, exp)
+
+
+def test_reference_four_match_rule_flag(ctx, orc):
+    """UWIP_OVERLAP_MIN4 (uwip_overlap_match_ex): the reference takes any homography findHomography returns for >= 4 good
+    matches (videostrip.cpp:252-272); the default needs >= 6 inliers.  Four consistent matches + one outlier (+ one query the
+    reference's loop bound skips, B-12): -2.0 by default, the oracle's overlap under the flag."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    n = 6
+    desc = rng.integers(0, 256, (n, 64), dtype=np.uint8)
+    desc[:, 60] &= 0x3f; desc[:, 61:] = 0
+    kq = np.zeros(n, vs.KP_DTYPE); kt = np.zeros(n, vs.KP_DTYPE)
+    kq["x"] = [100, 500, 120, 480, 300, 200]; kq["y"] = [60, 80, 300, 280, 180, 100]
+    kt["x"] = kq["x"] + 10; kt["y"] = kq["y"] - 5
+    kt["x"][4] += 80                                          # the outlier
+    for k in (kq, kt):
+        k["co"] = 1.0
+    f = vs.Features(ctx, 2)
+    ctx.call("uwip_features_upload", f._h, 0, 360, 640, C.c_void_p(kq.ctypes.data), C.c_void_p(desc.ctypes.data), n)
+    ctx.call("uwip_features_upload", f._h, 1, 360, 640, C.c_void_p(kt.ctypes.data), C.c_void_p(desc.ctypes.data), n)
+    r6 = vs.match_pairs(ctx, f, f, [0], [1], 640, 480, seed=1)
+    r4 = vs.match_pairs(ctx, f, f, [0], [1], 640, 480, seed=1, min4=True)
+    assert float(r6["ratio"].cpu()[0]) == -2.0
+    idx, dist = orc.match_knn2(desc, desc)
+    gq, gt = orc.ratio_test(idx, dist, n)
+    assert len(gq) == 5                                       # the last query is skipped (videostrip.cpp:235)
+    ninl, H = orc.find_homography(kq["x"][gq], kq["y"][gq], kt["x"][gt], kt["y"][gt], 640, 360, seed=1, min_inliers=4)
+    assert ninl == 4
+    er, _ = orc.overlapArea(H, 640, 480)
+    assert abs(float(r4["ratio"].cpu()[0]) - er) <= 1e-6 and int(r4["info"].cpu()[0][3]) == 4
+    f.close()
