@@ -499,7 +499,7 @@ template <class B> LM_HD inline int lmdif(const typename B::vec &y, int m, doubl
     constexpr int n = NP;
     const double ftol = 1.49012e-8, xtol = 1.49012e-8, gtol = 0.0, factor = 100.0;
     const int maxfev = 200 * (n + 1);
-    typename B::vec fvec, wa4, fjac[NP];
+    typename B::vec fvec{}, wa4{}, fjac[NP] = {};        // zeroed: slots >= m are swapped along with the columns
     double diag[NP], qtf[NP], wa1[NP], wa2[NP], wa3[NP], rmat[NP * NP];
     int ipvt[NP];
     int info = 0, nfev = 0;

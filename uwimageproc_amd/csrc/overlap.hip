@@ -2202,10 +2202,19 @@ UWIP_API int uwip_overlap_match_ex(uwip_ctx *ctx, const uwip_features *fq, const
     int32_t *m_dist = d_match_dist ? d_match_dist : (int32_t *)uwip_ws(ctx, "ov.mdist", sizeof(int32_t) * 2 * MAXKP * (size_t)npairs);
     int32_t *info = d_info ? d_info : (int32_t *)uwip_ws(ctx, "ov.info", sizeof(int32_t) * 8 * (size_t)npairs);
     if (!h_pairs || !d_pairs || !m_idx || !m_dist || !info) return UWIP_ERR_NOMEM;
-    UWIP_HIP(ctx, uwip_stream_wait(ctx));          // pinned staging reuse
-    memcpy(h_pairs, h_pair_q, sizeof(int32_t) * npairs);
-    memcpy(h_pairs + npairs, h_pair_t, sizeof(int32_t) * npairs);
-    UWIP_HIP(ctx, hipMemcpyAsync(d_pairs, h_pairs, sizeof(int32_t) * 2 * (size_t)npairs, hipMemcpyHostToDevice, ctx->stream));
+    // the same pair list as last time (every batch of a stream: frame i against frame i - 1) is already in d_pairs: nothing
+    // to stage, and the host does not have to wait for the stream before reusing the pinned buffer
+    const bool same = ctx->ov_pairs_dev == d_pairs && ctx->ov_pairs_host.size() == 2 * (size_t)npairs &&
+                      memcmp(ctx->ov_pairs_host.data(), h_pair_q, sizeof(int32_t) * npairs) == 0 &&
+                      memcmp(ctx->ov_pairs_host.data() + npairs, h_pair_t, sizeof(int32_t) * npairs) == 0;
+    if (!same) {
+        UWIP_HIP(ctx, uwip_stream_wait(ctx));          // pinned staging reuse
+        memcpy(h_pairs, h_pair_q, sizeof(int32_t) * npairs);
+        memcpy(h_pairs + npairs, h_pair_t, sizeof(int32_t) * npairs);
+        UWIP_HIP(ctx, hipMemcpyAsync(d_pairs, h_pairs, sizeof(int32_t) * 2 * (size_t)npairs, hipMemcpyHostToDevice, ctx->stream));
+        ctx->ov_pairs_host.assign(h_pairs, h_pairs + 2 * (size_t)npairs);
+        ctx->ov_pairs_dev = d_pairs;
+    }
     {
         uwip_kscope ks(ctx, "k_ov_match");
         constexpr int QT = 2;            // 2 query tiles of 16 per wave

@@ -36,6 +36,10 @@ struct uwip_ctx {
     // kernels whose > 64 KiB dynamic-LDS opt-in (hipFuncSetAttribute) has been made on this device
     std::map<std::string, bool> lds_optin;
     int ov_last_frames = 0;        // batch size of the most recent uwip_overlap_detect (debug taps)
+    // the pair list uwip_overlap_match last uploaded (a stream of batches sends the same one every time: no re-upload,
+    // and no host wait for the staging buffer)
+    std::vector<int32_t> ov_pairs_host;
+    const void *ov_pairs_dev = nullptr;
     // profiling
     bool prof = false;
     std::vector<uwip_prof_rec> prof_recs;
