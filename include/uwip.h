@@ -255,6 +255,9 @@ int uwip_aclahe_select(const float *h_entropy, int frames, int32_t *h_bs, int32_
  * Synchronises the stream once (the choice is a host decision). */
 int uwip_aclahe_auto(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst,
                      int residual_rule, int32_t *h_bs, int32_t *h_cl);
+/* The (BS, CL) the most recent uwip_aclahe_auto / uwip_aclahe_auto_ex on this context chose, h_bs / h_cl [frames] (frames =
+ * that call's frame count).  After a UWIP_ACLAHE_ASYNC call this waits for the stream and copies them from the device. */
+int uwip_aclahe_last_params(uwip_ctx *ctx, int32_t *h_bs, int32_t *h_cl, int frames);
 /* cv2.GaussianBlur(img, (3,3), 0) on 8UC1 planes, ACLAHE.py:15 (fixed [1 2 1]/4 kernel, BORDER_REFLECT_101; rounding of
  * the /16: rule 0 = half up, OpenCV 3.4.x's 8-bit fixed-point path; rule 1 = half to even, OpenCV 3.2's float path).
  * Not in place. */
@@ -273,6 +276,15 @@ int uwip_GaussianBlur3(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch
  *                                  parameters -- the two forms agree bit for bit.  Environment UWIP_ACLAHE_SELECT=host |
  *                                  device forces one form process-wide. */
 #define UWIP_ACLAHE_HOST_SELECT 2u
+/*   UWIP_ACLAHE_ASYNC              nothing comes back to the host and the call does not wait: the choice is made on the device,
+ *                                  the final per-frame CLAHE is launched from the device-side parameters (the kernels of all
+ *                                  five grids are launched over the batch, blocks of frames that chose another grid exit),
+ *                                  and a frame whose clip limit leaves the swept grid gets its exact block-size search from a
+ *                                  device kernel.  h_bs / h_cl must be NULL; uwip_aclahe_last_params fetches the parameters
+ *                                  later (it waits for the stream).  Same image, same parameters as the other forms.  Batches
+ *                                  the library gives to the host form (<= 4 frames, UWIP_ACLAHE_SELECT=host) run synchronously
+ *                                  under this flag too. */
+#define UWIP_ACLAHE_ASYNC 4u
 int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst,
                         int residual_rule, unsigned flags, int32_t *h_bs, int32_t *h_cl);
 

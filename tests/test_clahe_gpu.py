@@ -398,3 +398,61 @@ def test_aclahe_auto_device_and_host_choice_agree(ctx, orc):
         ctx.sync()
         outs.append((list(zip(bs, cl)), dst.cpu().numpy()))
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+
+
+def _auto(ctx, t, flags):
+    import ctypes as C
+    from uwimageproc_amd import batch_of
+    F = t.shape[0]
+    dst = torch.empty_like(t)
+    sb, db = batch_of(t), batch_of(dst)
+    if flags & 4:                                            # UWIP_ACLAHE_ASYNC: parameters fetched afterwards
+        ctx.call("uwip_aclahe_auto_ex", C.byref(sb), C.byref(db), 0, flags, None, None)
+        bs, cl = (C.c_int32 * F)(), (C.c_int32 * F)()
+        ctx.call("uwip_aclahe_last_params", bs, cl, F)
+    else:
+        bs, cl = (C.c_int32 * F)(), (C.c_int32 * F)()
+        ctx.call("uwip_aclahe_auto_ex", C.byref(sb), C.byref(db), 0, flags, bs, cl)
+    ctx.sync()
+    return list(zip(bs, cl)), dst.cpu().numpy()
+
+
+@pytest.mark.parametrize("shape", [(270, 480), (1080, 1920)])
+def test_aclahe_async_equals_synchronous_forms(ctx, orc, shape, monkeypatch):
+    """UWIP_ACLAHE_ASYNC (the choice on the device, the final CLAHE launched from device-side parameters, no host wait)
+    against the synchronous device-choice form and the host form: same parameters, same bytes.  The frames are made to
+    choose different block sizes (contrast / texture vary), so several of the five predicated grids take part; then the
+    out-of-grid path: a forced clip limit of 30 (UWIP_ACLAHE_TEST_FORCE_CL) sends every frame through the exact block-size
+    search -- k_aclahe_exact_bs on the device against the host-ordered CLAHE + entropy runs."""
+    rows, cols = shape
+    rng = np.random.default_rng(5)
+    F = 8
+    frames = np.stack([_v(orc, 500 + i, rows, cols) for i in range(F)])
+    frames[1] = rng.integers(0, 256, (rows, cols), dtype=np.uint8)                       # noise
+    frames[2] = (frames[2] // 32) * 32                                                   # posterised
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    frames[3] = ((xx * 255) // cols).astype(np.uint8)                                    # ramp
+    frames[4] = np.where((xx // 40 + yy // 40) % 2 == 0, 60, 190).astype(np.uint8)       # checkerboard
+    frames[5] = np.clip(128 + 60 * np.sin(xx / 17.0) * np.cos(yy / 11.0) + rng.normal(0, 6, (rows, cols)), 0, 255).astype(np.uint8)
+    t = _dev(frames)
+    p_sync, o_sync = _auto(ctx, t, 1)
+    p_host, o_host = _auto(ctx, t, 1 | 2)
+    p_async, o_async = _auto(ctx, t, 1 | 4)
+    assert p_sync == p_host == p_async, (p_sync, p_host, p_async)
+    assert np.array_equal(o_sync, o_host) and np.array_equal(o_sync, o_async)
+    assert len({bs for bs, _ in p_async}) >= 2, p_async                                  # more than one grid took part
+    # the parameters again, against the oracle chain for one frame
+    bs, cl = knee_mirror.select_parameters(orc.sweep(orc.gaussian3(frames[0])))
+    assert p_async[0] == (bs, cl)
+    # (the hook acts in the device choice; the synchronous forms re-select on the host for such frames, so the check here is
+    # against the oracle: BS = last arg-max of the float16 entropies of CLAHE(blurred plane, 30, g), output = CLAHE(plane, 30, BS))
+    monkeypatch.setenv("UWIP_ACLAHE_TEST_FORCE_CL", "30")
+    q_async, r_async = _auto(ctx, t, 1 | 4)
+    monkeypatch.delenv("UWIP_ACLAHE_TEST_FORCE_CL")
+    assert all(c == 30 for _, c in q_async), q_async
+    for f in range(F if rows < 1000 else 2):
+        filt = orc.gaussian3(frames[f])
+        ent = np.array([orc.entropy(orc.clahe(filt, 30.0, g, g)) for g in (2, 4, 8, 16, 32)], np.float32).astype(np.float16)
+        want = (2, 4, 8, 16, 32)[int(np.nonzero(ent == ent.max())[0][-1])]
+        assert q_async[f][0] == want, (f, q_async[f], ent)
+        assert np.array_equal(r_async[f], orc.clahe(frames[f], 30.0, want, want)), f

@@ -90,6 +90,7 @@ SIGNATURES = {
     "uwip_aclahe_sweep": (C.c_int, [_P, _B, C.c_int, _P]),
     "uwip_aclahe_sweep_hist": (C.c_int, [_P, _B, C.c_int, _P, _P]),
     "uwip_aclahe_knee": (C.c_int, [C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_int32)]),
+    "uwip_aclahe_last_params": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]),
     "uwip_aclahe_select_device": (C.c_int, [_P, _P, C.c_int, _P, _P]),
     "uwip_host_pool_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     "uwip_aclahe_select": (C.c_int, [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

@@ -6,7 +6,7 @@
 // the last maximum winning).
 #include "uwip_internal.hpp"
 #include "lm_core.hpp"
-#include <mutex>
+#include <cstdlib>
 
 namespace {
 
@@ -39,13 +39,14 @@ __device__ inline float through_half_dev(float f) { return (float)(_Float16)f; }
 
 // par [F][4] = {BS, CL, needs an evaluation outside the swept grid, 0}
 __global__ __launch_bounds__(64) void k_aclahe_choose(const float *__restrict__ tab, const int32_t *__restrict__ knee, int F,
-                                                     int32_t *__restrict__ par)
+                                                     int32_t *__restrict__ par, int force_d)
 {
     const int f = blockIdx.x * 64 + threadIdx.x;
     if (f >= F) return;
     int d = -1;
     for (int g = 0; g < 5; ++g) d = max(d, knee[(size_t)f * 5 + g]);
     if (d < 0) d = 0;
+    if (force_d >= 0) d = force_d;                  // test hook (UWIP_ACLAHE_TEST_FORCE_CL): exercises the out-of-grid path
     const bool outside = 2 * d > 50;
     int w = 0;
     float best = 0.f;
@@ -88,7 +89,10 @@ UWIP_API int uwip_aclahe_select_device(uwip_ctx *ctx, const float *d_entropy, in
     }
     {
         uwip_kscope ks(ctx, "k_aclahe_choose");
-        k_aclahe_choose<<<uwip_cdiv(frames, 64), 64, 0, ctx->stream>>>(d_entropy, knee, frames, d_par);
+        // a knee index >= 26 takes a degenerate fit: the tests force one to reach the exact block-size search
+        const char *fe = std::getenv("UWIP_ACLAHE_TEST_FORCE_CL");
+        const int force_d = fe && *fe ? std::atoi(fe) : -1;
+        k_aclahe_choose<<<uwip_cdiv(frames, 64), 64, 0, ctx->stream>>>(d_entropy, knee, frames, d_par, force_d);
         UWIP_HIP(ctx, hipGetLastError());
     }
     return UWIP_OK;

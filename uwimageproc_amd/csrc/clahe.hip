@@ -217,8 +217,10 @@ __global__ __launch_bounds__(256) void k_clahe_tilehist(const uint8_t *__restric
                                                         int cols, int gx, int tw, int th, int split,
                                                         int rows_per_part,
                                                         const int *__restrict__ frame_map,
-                                                        uint32_t *__restrict__ hists, int tiles)
+                                                        uint32_t *__restrict__ hists, int tiles,
+                                                        const int *__restrict__ nf_dev /*optional: frames that take part*/)
 {
+    if (nf_dev && (int)blockIdx.y >= *nf_dev) return;
     constexpr bool BP = FORM != 0;
     constexpr int HWORDS = BP ? TH_BP_WORDS : TH_REP * TH_RSTRIDE;
     __shared__ __attribute__((aligned(16))) uint32_t sh[4][HWORDS];
@@ -470,12 +472,14 @@ __device__ __forceinline__ void clahe_lut_rows(const int (&h0)[4], int lane, flo
 __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ hists, int tiles, int nf,
                                                    float lutScale, ClipList cl,
                                                    const int *__restrict__ frame_clip, int rule,
-                                                   uint8_t *__restrict__ luts, uint32_t *__restrict__ tile_max /*optional*/)
+                                                   uint8_t *__restrict__ luts, uint32_t *__restrict__ tile_max /*optional*/,
+                                                   const int *__restrict__ nf_dev /*optional*/)
 {
     const int lane = threadIdx.x & 63;
     const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wv >= (long long)tiles * nf) return;
     const int f = (int)(wv / tiles), t = (int)(wv - (long long)f * tiles);
+    if (nf_dev && f >= *nf_dev) return;
     const uint4 hv = *reinterpret_cast<const uint4 *>(hists + ((size_t)f * tiles + t) * 256 + lane * 4);
     const int h0[4] = {(int)hv.x, (int)hv.y, (int)hv.z, (int)hv.w};
     // [frame][tile][clip limit][256]: the wave's rows are one contiguous run (ncl = 1: the plain [frame][tile][256] table)
@@ -500,8 +504,10 @@ template <int CHUNKS>       // 64-unit chunks per image row (1, 2, 4, 8); BAND_T
 __global__ __launch_bounds__(BAND_THREADS) void k_clahe_band(const uint8_t *__restrict__ src, size_t step, size_t fstride, int rows, int cols,
                                                              int gx, int tw, uint32_t tw_magic, int th, const int *__restrict__ frame_map, float lutScale,
                                                              ClipList cl, const int *__restrict__ frame_clip, int rule,
-                                                             uint8_t *__restrict__ luts, uint32_t *__restrict__ tile_max, int tiles)
+                                                             uint8_t *__restrict__ luts, uint32_t *__restrict__ tile_max, int tiles,
+                                                             const int *__restrict__ nf_dev /*optional*/)
 {
+    if (nf_dev && (int)blockIdx.y >= *nf_dev) return;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_band[];      // [gx][BAND_TSTRIDE]
     struct __attribute__((packed, aligned(1))) U16 { uint32_t x, y, z, w; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1008,7 +1014,7 @@ bool aligned_for(const uwip_batch_u8 *b, size_t a)
 }
 
 int launch_tilehist(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g, const int *d_frame_map,
-                    int nf, uint32_t *d_hists)
+                    int nf, uint32_t *d_hists, const int *d_nf = nullptr)
 {
     const int tiles = g.gx * g.gy;
     // one wave per (tile, row part).  Large aligned tiles take the slot-keyed form: parts of >= TH_BP_MIN pixels, enough of
@@ -1042,23 +1048,23 @@ int launch_tilehist(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g,
     static const bool no_general = [] { const char *e = std::getenv("UWIP_TILEHIST_GENERAL"); return e && *e == '0'; }();    // A/B
     if (bp)
         k_clahe_tilehist<1><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.rows, g.cols,
-                                                           g.gx, g.tw, g.th, split, rpp, d_frame_map, d_hists, tiles);
+                                                           g.gx, g.tw, g.th, split, rpp, d_frame_map, d_hists, tiles, d_nf);
     else if (bpg && !no_general)
         k_clahe_tilehist<2><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.rows, g.cols,
-                                                           g.gx, g.tw, g.th, split, rpp, d_frame_map, d_hists, tiles);
+                                                           g.gx, g.tw, g.th, split, rpp, d_frame_map, d_hists, tiles, d_nf);
     else
         k_clahe_tilehist<0><<<grid, 256, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.rows, g.cols,
-                                                           g.gx, g.tw, g.th, split, rpp, d_frame_map, d_hists, tiles);
+                                                           g.gx, g.tw, g.th, split, rpp, d_frame_map, d_hists, tiles, d_nf);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
 
 int launch_lut(uwip_ctx *ctx, const ClaheGeom &g, const uint32_t *d_hists, const ClipList &cl,
-               const int *d_frame_clip, int nf, int rule, uint8_t *d_luts, uint32_t *d_tile_max = nullptr)
+               const int *d_frame_clip, int nf, int rule, uint8_t *d_luts, uint32_t *d_tile_max = nullptr, const int *d_nf = nullptr)
 {
     const int tiles = g.gx * g.gy;
     uwip_kscope ks(ctx, "k_clahe_lut");
-    k_clahe_lut<<<uwip_cdiv((size_t)tiles * nf, 4), 256, 0, ctx->stream>>>(d_hists, tiles, nf, g.lutScale, cl, d_frame_clip, rule, d_luts, d_tile_max);
+    k_clahe_lut<<<uwip_cdiv((size_t)tiles * nf, 4), 256, 0, ctx->stream>>>(d_hists, tiles, nf, g.lutScale, cl, d_frame_clip, rule, d_luts, d_tile_max, d_nf);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
@@ -1074,7 +1080,7 @@ bool band_ok(const uwip_batch_u8 *src, const ClaheGeom &g)
 }
 
 int launch_band(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g, const int *d_frame_map, int nf, const ClipList &cl,
-                const int *d_frame_clip, int rule, uint8_t *d_luts, uint32_t *d_tile_max)
+                const int *d_frame_clip, int rule, uint8_t *d_luts, uint32_t *d_tile_max, const int *d_nf = nullptr)
 {
     const int nu = (g.cols + 15) >> 4;
     const int chunks = nu <= 64 ? 1 : (nu <= 128 ? 2 : (nu <= 256 ? 4 : 8));
@@ -1089,7 +1095,7 @@ int launch_band(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g, con
         if (rc_l) return rc_l;                                                                                                         \
         k_clahe_band<C><<<grid, BAND_THREADS, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.rows, g.cols, \
                                                                g.gx, g.tw, magic, g.th, d_frame_map, g.lutScale, cl, d_frame_clip, rule, \
-                                                               d_luts, d_tile_max, tiles);                                              \
+                                                               d_luts, d_tile_max, tiles, d_nf);                                        \
     } while (0)
     switch (chunks) {
     case 1: UWIP_BAND(1); break;
@@ -1193,6 +1199,128 @@ int launch_apply_mixed(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch
                                                               0.f, 0.f, nullptr, 0, nullptr, nullptr, 0, 1, d_desc);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
+}
+
+// ---- the block-size search at a clip limit OUTSIDE the swept grid, on the device (ACLAHE.py:102-112) -----------------------
+// A knee index d >= 26 makes d itself (the reference uses the index as a clip limit) leave the sweep's 0 .. 25: the five
+// entropies at that clip limit are then evaluated for the frame.  It takes a degenerate fit to get here, so
+// this is written for correctness, not speed: ONE block per flagged frame walks the five grids -- tile histograms by global
+// atomics into the frame's slice of the tile-histogram workspace, LUT rows by clahe_lut_rows, the CLAHE output of every pixel
+// (cv::CLAHE's float32 blend, the operations of k_clahe_apply) counted into a 256-bin LDS histogram without being stored,
+// aclaheEntropy (k_entropy's operations) -- and rewrites the frame's BS.  Blocks of unflagged frames exit at once.
+struct ExactGrids {
+    int g[5], tw[5], th[5], pc[5], pr[5], area[5];
+    float inv_tw[5], inv_th[5], lutScale[5];
+};
+__global__ __launch_bounds__(512) void k_aclahe_exact_bs(const uint8_t *__restrict__ src, size_t step, size_t fstride, int rows, int cols,
+                                                        ExactGrids G, int rule, int32_t *__restrict__ par /*[F][4]*/,
+                                                        uint32_t *__restrict__ hist_ws /*[F][1024][256]*/, uint8_t *__restrict__ lut_ws /*[F][1024][256]*/)
+{
+    const int f = blockIdx.x;
+    if (par[4 * f + 2] != 1) return;
+    __shared__ uint32_t s_out[256];
+    __shared__ float s_ent[5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = par[4 * f + 1];
+    const uint8_t *plane = src + (size_t)f * fstride;
+    uint32_t *hist = hist_ws + (size_t)f * 1024 * 256;
+    uint8_t *lut = lut_ws + (size_t)f * 1024 * 256;
+    for (int k = 0; k < 5; ++k) {
+        const int gx = G.g[k], gy = G.g[k], tiles = gx * gy, tw = G.tw[k], th = G.th[k], pc = G.pc[k], pr = G.pr[k];
+        for (int i = tid; i < tiles * 256; i += 512) hist[i] = 0;
+        if (tid < 256) s_out[tid] = 0;
+        __threadfence();
+        __syncthreads();
+        for (int i = tid; i < pc * pr; i += 512) {
+            const int y = i / pc, x = i - y * pc;
+            const uint32_t v = plane[(size_t)reflect101(y, rows) * step + reflect101(x, cols)];
+            atomicAdd(&hist[((y / th) * gx + x / tw) * 256 + v], 1u);
+        }
+        __threadfence();
+        __syncthreads();
+        int clip = 0;                                  // clip_from_limit((double)d, area)
+        if (d > 0) { clip = (int)((double)d * G.area[k] / 256); clip = max(clip, 1); }
+        ClipList cl;
+        cl.n = 1;
+        for (int t = wave; t < tiles; t += 8) {
+            const uint4 hv = *reinterpret_cast<const uint4 *>(hist + (size_t)t * 256 + lane * 4);
+            const int h0[4] = {(int)hv.x, (int)hv.y, (int)hv.z, (int)hv.w};
+            clahe_lut_rows(h0, lane, G.lutScale[k], cl, clip, rule, lut + (size_t)t * 256, nullptr);
+        }
+        __threadfence();
+        __syncthreads();
+        const float inv_tw = G.inv_tw[k], inv_th = G.inv_th[k];
+        for (int i = tid; i < rows * cols; i += 512) {
+            const int y = i / cols, x = i - y * cols;
+            const uint32_t v = plane[(size_t)y * step + x];
+            const float txf = (float)x * inv_tw - 0.5f, tyf = (float)y * inv_th - 0.5f;
+            const float flx = floorf(txf), fly = floorf(tyf);
+            const float xa = txf - flx, xa1 = 1.0f - xa, ya = tyf - fly, ya1 = 1.0f - ya;
+            const int tx1 = max((int)flx, 0), tx2 = min((int)flx + 1, gx - 1), ty1 = max((int)fly, 0), ty2 = min((int)fly + 1, gy - 1);
+            const float TL = (float)lut[(size_t)(ty1 * gx + tx1) * 256 + v], TR = (float)lut[(size_t)(ty1 * gx + tx2) * 256 + v];
+            const float BL = (float)lut[(size_t)(ty2 * gx + tx1) * 256 + v], BR = (float)lut[(size_t)(ty2 * gx + tx2) * 256 + v];
+            const float res = (TL * xa1 + TR * xa) * ya1 + (BL * xa1 + BR * xa) * ya;
+            atomicAdd(&s_out[__builtin_amdgcn_cvt_pk_u8_f32(res, 0, 0u)], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {                                // aclaheEntropy, aclahe.cpp:241-247
+            float e = 0.0f;
+            for (int i = 0; i < 256; ++i) {
+                const float p = (float)s_out[i] / (float)(cols * rows);
+                e = (float)((double)e + (double)p * log2((double)p + 0.00001));
+            }
+            s_ent[k] = -e;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        int w = 0;
+        float best = 0.f;
+        for (int k = 0; k < 5; ++k) {
+            const float h = (float)(_Float16)s_ent[k];
+            if (k == 0 || h >= best) { best = h; w = k; }          // last maximum wins (ACLAHE.py:118-124)
+        }
+        par[4 * f + 0] = G.g[w];
+        par[4 * f + 2] = 2;                                          // evaluated
+    }
+}
+
+// ---- the final CLAHE of the aclahe stage launched from DEVICE-side parameters (round 4) -------------------------------------
+// The parameter choice is made on the device (aclahe_device.hip); to launch the per-frame CLAHE without bringing {BS, CL}
+// back, everything the host used to derive from them is derived here: the frames are grouped by block size (group k =
+// block size 2, 4, 8, 16, 32, frame order kept), every group gets its frame map, clip limits and frame count, every frame
+// its interpolation descriptor.  The host then launches the tile-histogram / LUT kernels of ALL five grids over the whole
+// batch -- a block whose frame index is beyond its group's count exits at once -- and the one mixed interpolation launch.
+struct PfGrids {
+    const int4 *strips[5];
+    uint8_t *luts[5];
+    int *map[5], *clip[5];
+    int nstrips[5], g[5], TX[5], xs[5], area[5], tiles[5];
+    float inv_tw[5], inv_th[5];
+};
+__global__ void k_pf_prepare(const int32_t *__restrict__ par /*[F][4] = BS, CL, ..*/, int F, PfGrids G, int *__restrict__ count /*[5]*/,
+                             ApplyFrame *__restrict__ desc)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int cnt[5] = {0, 0, 0, 0, 0};
+    for (int f = 0; f < F; ++f) {                   // a sub-batch: a serial walk keeps every group in frame order
+        const int bs = par[4 * f], cl = par[4 * f + 1];
+        const int k = bs == 2 ? 0 : (bs == 4 ? 1 : (bs == 8 ? 2 : (bs == 16 ? 3 : 4)));
+        int i = 0;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) if (q == k) i = cnt[q]++;
+        G.map[k][i] = f;
+        int clip = 0;                                // clip_from_limit((double)cl, area)
+        if (cl > 0) { clip = (int)((double)cl * G.area[k] / 256); clip = max(clip, 1); }
+        G.clip[k][i] = clip;
+        ApplyFrame a;
+        a.strips = G.strips[k]; a.luts = G.luts[k] + (size_t)i * G.tiles[k] * 256; a.fr = f;
+        a.nstrips = G.nstrips[k]; a.gx = G.g[k]; a.gy = G.g[k]; a.TX = G.TX[k]; a.xs = G.xs[k];
+        a.inv_tw = G.inv_tw[k]; a.inv_th = G.inv_th[k];
+        desc[f] = a;
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) count[q] = cnt[q];
 }
 
 int check_pair(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst)
@@ -1373,6 +1501,89 @@ UWIP_API int uwip_clahe_per_frame(uwip_ctx *ctx, const uwip_batch_u8 *src, const
     return launch_apply_mixed(ctx, src, dst, d_desc, F, max_blocks, max_cells);
 }
 
+// the exact block-size search for the frames uwip_aclahe_select_device flagged (one predicated launch; see k_aclahe_exact_bs)
+static int aclahe_exact_bs_device(uwip_ctx *ctx, const uwip_batch_u8 *src, int32_t *d_par, int residual_rule)
+{
+    static const int BlockSize[5] = {2, 4, 8, 16, 32};
+    const int F = src->frames;
+    ExactGrids G{};
+    for (int k = 0; k < 5; ++k) {
+        const ClaheGeom g = make_geom(src->rows, src->cols, BlockSize[k], BlockSize[k]);
+        G.g[k] = BlockSize[k]; G.tw[k] = g.tw; G.th[k] = g.th; G.pc[k] = g.pc; G.pr[k] = g.pr; G.area[k] = g.area;
+        G.inv_tw[k] = g.inv_tw; G.inv_th[k] = g.inv_th; G.lutScale[k] = g.lutScale;
+    }
+    uint32_t *d_hists = (uint32_t *)uwip_ws(ctx, "clahe.tilehist", sizeof(uint32_t) * 256 * (size_t)1024 * F);
+    uint8_t *d_luts = (uint8_t *)uwip_ws(ctx, "sweep.luts", (size_t)256 * 1024 * SWEEP_NCL * F);
+    if (!d_hists || !d_luts) return UWIP_ERR_NOMEM;
+    uwip_kscope ks(ctx, "k_aclahe_exact_bs");
+    k_aclahe_exact_bs<<<F, 512, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, src->rows, src->cols, G,
+                                                  residual_rule, d_par, d_hists, d_luts);
+    UWIP_HIP(ctx, hipGetLastError());
+    return UWIP_OK;
+}
+
+// createCLAHE(CL, (BS, BS)).apply per frame with {BS, CL} read from device memory (d_par [F][4]): no host wait, no copy
+static int clahe_per_frame_device(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, const int32_t *d_par, int residual_rule)
+{
+    static const int BlockSize[5] = {2, 4, 8, 16, 32};
+    int rc = check_pair(ctx, src, dst);
+    if (rc) return rc;
+    if (uwip_batch_empty(src)) return UWIP_OK;
+    const int F = src->frames;
+    ClaheGeom g[5];
+    ApplyShape sh[5];
+    PfGrids G{};
+    size_t lut_bytes = 0;
+    for (int k = 0; k < 5; ++k) {
+        rc = check_grid(ctx, BlockSize[k], BlockSize[k]);
+        if (rc) return rc;
+        g[k] = make_geom(src->rows, src->cols, BlockSize[k], BlockSize[k]);
+        sh[k] = apply_shape(g[k]);
+        lut_bytes += (size_t)BlockSize[k] * BlockSize[k] * 256 * F;
+    }
+    uint32_t *d_hists = (uint32_t *)uwip_ws(ctx, "clahe.tilehist", sizeof(uint32_t) * 256 * (size_t)1024 * F);
+    uint8_t *d_luts = (uint8_t *)uwip_ws(ctx, "clahe.pfd.luts", lut_bytes);
+    int *d_ints = (int *)uwip_ws(ctx, "clahe.pfd.ints", sizeof(int) * (10 * (size_t)F + 8));
+    ApplyFrame *d_desc = (ApplyFrame *)uwip_ws(ctx, "clahe.pf.desc", sizeof(ApplyFrame) * (size_t)F);
+    if (!d_hists || !d_luts || !d_ints || !d_desc) return UWIP_ERR_NOMEM;
+    int *d_count = d_ints + 10 * (size_t)F;
+    int max_blocks = 0, max_cells = 0;
+    size_t loff = 0;
+    for (int k = 0; k < 5; ++k) {
+        const int4 *d_strips = nullptr;
+        int nstrips = 0;
+        rc = build_strips(ctx, g[k], sh[k].max_rows, &d_strips, &nstrips);
+        if (rc) return rc;
+        G.strips[k] = d_strips; G.nstrips[k] = nstrips; G.g[k] = BlockSize[k]; G.TX[k] = sh[k].TX; G.xs[k] = sh[k].xs;
+        G.area[k] = g[k].area; G.tiles[k] = BlockSize[k] * BlockSize[k]; G.inv_tw[k] = g[k].inv_tw; G.inv_th[k] = g[k].inv_th;
+        G.luts[k] = d_luts + loff;
+        loff += (size_t)G.tiles[k] * 256 * F;
+        G.map[k] = d_ints + (size_t)k * F;
+        G.clip[k] = d_ints + (size_t)(5 + k) * F;
+        max_blocks = std::max(max_blocks, nstrips * sh[k].xs);
+        max_cells = std::max(max_cells, sh[k].lds_cells);
+    }
+    {
+        uwip_kscope ks(ctx, "k_pf_prepare");
+        k_pf_prepare<<<1, 64, 0, ctx->stream>>>(d_par, F, G, d_count, d_desc);
+        UWIP_HIP(ctx, hipGetLastError());
+    }
+    ClipList cl{};
+    cl.n = 1;
+    for (int k = 0; k < 5; ++k) {
+        if (band_ok(src, g[k])) {
+            rc = launch_band(ctx, src, g[k], G.map[k], F, cl, G.clip[k], residual_rule, G.luts[k], nullptr, d_count + k);
+            if (rc) return rc;
+        } else {
+            rc = launch_tilehist(ctx, src, g[k], G.map[k], F, d_hists, d_count + k);
+            if (rc) return rc;
+            rc = launch_lut(ctx, g[k], d_hists, cl, G.clip[k], F, residual_rule, G.luts[k], nullptr, d_count + k);
+            if (rc) return rc;
+        }
+    }
+    return launch_apply_mixed(ctx, src, dst, d_desc, F, max_blocks, max_cells);
+}
+
 UWIP_API int uwip_entropy(uwip_ctx *ctx, const uwip_batch_u8 *src, float *d_entropy)
 {
     int rc = uwip_check_batch(ctx, src, 1);
@@ -1517,7 +1728,8 @@ UWIP_API int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const 
     if (rc) return rc;
     if (img->frames == 0) return UWIP_OK;
     UWIP_REQUIRE(ctx, !uwip_batch_empty(img), "aclahe of an empty image");
-    UWIP_REQUIRE(ctx, (flags & ~(unsigned)(UWIP_ACLAHE_PREFILTER | UWIP_ACLAHE_HOST_SELECT)) == 0, "unknown flag");
+    UWIP_REQUIRE(ctx, (flags & ~(unsigned)(UWIP_ACLAHE_PREFILTER | UWIP_ACLAHE_HOST_SELECT | UWIP_ACLAHE_ASYNC)) == 0, "unknown flag");
+    UWIP_REQUIRE(ctx, !(flags & UWIP_ACLAHE_ASYNC) || (!h_bs && !h_cl), "UWIP_ACLAHE_ASYNC: the parameters are fetched with uwip_aclahe_last_params");
     const int F = img->frames;
     // Where the choice is made.  Default: on the device (no table copy, no host computation: 0.25 CPU-seconds per 512-frame
     // step and rank otherwise) -- except for batches of a few frames, where latency is what matters (the paced 4K@60 stream
@@ -1548,9 +1760,23 @@ UWIP_API int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const 
     float *extra = (float *)(h_par + 4 * F);
     double *clip = (double *)(extra + 5 * F);
     bool any = false;
+    ctx->aclahe_last_n = F;
+    ctx->aclahe_last_on_device = false;
+    if (!host_select && (flags & UWIP_ACLAHE_ASYNC)) {
+        // nothing comes back to the host: the choice (aclahe_device.hip) and the launch of the final CLAHE from the
+        // device-side parameters (clahe_per_frame_device) are queued behind the sweep, and the call returns
+        int32_t *d_par = (int32_t *)uwip_ws(ctx, "auto.par", sizeof(int32_t) * 4 * (size_t)F);
+        if (!d_par) return UWIP_ERR_NOMEM;
+        rc = uwip_aclahe_select_device(ctx, d_ent, F, d_par, nullptr);
+        if (rc) return rc;
+        rc = aclahe_exact_bs_device(ctx, src, d_par, residual_rule);
+        if (rc) return rc;
+        ctx->aclahe_last_on_device = true;
+        return clahe_per_frame_device(ctx, img, dst, d_par, residual_rule);
+    }
     if (!host_select) {
         // the choice on the device (aclahe_device.hip): only {BS, CL, need} per frame come back -- the launch geometry of
-        // the final CLAHE depends on them, which is the one reason the host still waits here
+        // the final CLAHE depends on them
         int32_t *d_par = (int32_t *)uwip_ws(ctx, "auto.par", sizeof(int32_t) * 4 * (size_t)F);
         int32_t *h_dpar = (int32_t *)uwip_host_ws(ctx, "auto.dpar", sizeof(int32_t) * 4 * (size_t)F);
         if (!d_par || !h_dpar) return UWIP_ERR_NOMEM;
@@ -1602,7 +1828,30 @@ UWIP_API int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const 
     for (int f = 0; f < F; ++f) clip[f] = (double)cl[f];
     if (h_bs) for (int f = 0; f < F; ++f) h_bs[f] = bs[f];
     if (h_cl) for (int f = 0; f < F; ++f) h_cl[f] = cl[f];
+    ctx->aclahe_last_host.resize(2 * (size_t)F);
+    for (int f = 0; f < F; ++f) { ctx->aclahe_last_host[2 * f] = bs[f]; ctx->aclahe_last_host[2 * f + 1] = cl[f]; }
     return uwip_clahe_per_frame(ctx, img, dst, clip, bs, residual_rule);
+}
+
+// the parameters of the most recent uwip_aclahe_auto_ex on this context (waits for the stream when they are still on the device)
+UWIP_API int uwip_aclahe_last_params(uwip_ctx *ctx, int32_t *h_bs, int32_t *h_cl, int frames)
+{
+    if (int rc_e = uwip_enter(ctx)) return rc_e;
+    UWIP_REQUIRE(ctx, frames == ctx->aclahe_last_n, "frame count differs from the last uwip_aclahe_auto_ex");
+    if (frames == 0) return UWIP_OK;
+    UWIP_REQUIRE(ctx, h_bs && h_cl, "null output");
+    if (ctx->aclahe_last_on_device) {
+        const int32_t *d_par = (const int32_t *)uwip_ws(ctx, "auto.par", sizeof(int32_t) * 4 * (size_t)frames);
+        int32_t *h = (int32_t *)uwip_host_ws(ctx, "auto.dpar", sizeof(int32_t) * 4 * (size_t)frames);
+        if (!d_par || !h) return UWIP_ERR_NOMEM;
+        UWIP_HIP(ctx, hipMemcpyAsync(h, d_par, sizeof(int32_t) * 4 * (size_t)frames, hipMemcpyDeviceToHost, ctx->stream));
+        UWIP_HIP(ctx, uwip_stream_wait(ctx));
+        for (int f = 0; f < frames; ++f) { h_bs[f] = h[4 * f]; h_cl[f] = h[4 * f + 1]; }
+        return UWIP_OK;
+    }
+    UWIP_REQUIRE(ctx, ctx->aclahe_last_host.size() == 2 * (size_t)frames, "no parameters recorded");
+    for (int f = 0; f < frames; ++f) { h_bs[f] = ctx->aclahe_last_host[2 * f]; h_cl[f] = ctx->aclahe_last_host[2 * f + 1]; }
+    return UWIP_OK;
 }
 
 UWIP_API int uwip_aclahe_auto(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int residual_rule,

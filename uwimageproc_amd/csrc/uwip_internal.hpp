@@ -36,6 +36,11 @@ struct uwip_ctx {
     // kernels whose > 64 KiB dynamic-LDS opt-in (hipFuncSetAttribute) has been made on this device
     std::map<std::string, bool> lds_optin;
     int ov_last_frames = 0;        // batch size of the most recent uwip_overlap_detect (debug taps)
+    // the parameters the most recent uwip_aclahe_auto_ex chose: on the host (the synchronous forms) or still on the device
+    // (UWIP_ACLAHE_ASYNC: workspace "auto.par", [n][4] int32) -- uwip_aclahe_last_params
+    int aclahe_last_n = 0;
+    bool aclahe_last_on_device = false;
+    std::vector<int32_t> aclahe_last_host;      // [n][2] = BS, CL
     // the pair list uwip_overlap_match last uploaded (a stream of batches sends the same one every time: no re-upload,
     // and no host wait for the staging buffer)
     std::vector<int32_t> ov_pairs_host;

@@ -21,6 +21,7 @@ import torch
 from ._native import Context, Copier, batch_of
 
 DEHAZE_FULL, DEHAZE_GUARD_S = 1, 2
+ACLAHE_PREFILTER, ACLAHE_ASYNC = 1, 4          # uwip.h
 
 
 class FramePipe:
@@ -47,7 +48,8 @@ class FramePipe:
         self.info = torch.zeros((frames, 8), dtype=torch.int32, device=self.dev)
         self.h_bs = (C.c_int32 * frames)()
         self.h_cl = (C.c_int32 * frames)()
-        self.params = []
+        self._params = None
+        self._inflight = []
         # feature slots: 0 = previous batch's last frame, 1..F = this batch
         fh = C.c_void_p()
         self.ctx.call("uwip_features_create", frames + 1, C.byref(fh))
@@ -89,11 +91,21 @@ class FramePipe:
     def stage_aclahe(self):
         wb, vb, ob = batch_of(self.work), batch_of(self.v), batch_of(self.v_out)
         self.ctx.call("uwip_bgr_to_v", C.byref(wb), C.byref(vb))
-        # sweep -> host parameter choice (native MINPACK restatement) -> per-frame CLAHE
+        # sweep -> parameter choice -> per-frame CLAHE, all queued on the stream (UWIP_ACLAHE_ASYNC: the choice is made on
+        # the device and the final CLAHE is launched from the device-side parameters; nothing comes back, the host does not
+        # wait -- `params` fetches (BS, CL) when somebody asks).
         # ParametrosACLAHE: the search runs on the 3x3-blurred V (ACLAHE.py:15), the final CLAHE on V itself (main.py:19-20)
-        self.ctx.call("uwip_aclahe_auto_ex", C.byref(vb), C.byref(ob), 0, 1, self.h_bs, self.h_cl)
-        self.params = list(zip(self.h_bs, self.h_cl))
+        self.ctx.call("uwip_aclahe_auto_ex", C.byref(vb), C.byref(ob), 0, ACLAHE_PREFILTER | ACLAHE_ASYNC, None, None)
+        self._params = None
         self.ctx.call("uwip_hsv_replace_v", C.byref(wb), C.byref(ob), C.byref(wb))
+
+    @property
+    def params(self):
+        """[(BS, CL)] of the most recent aclahe stage (waits for the stream the first time it is read after a stage)"""
+        if self._params is None:
+            self.ctx.call("uwip_aclahe_last_params", self.h_bs, self.h_cl, self.F)
+            self._params = list(zip(self.h_bs, self.h_cl))
+        return self._params
 
     def stage_overlap(self):
         wb = batch_of(self.work)
@@ -189,7 +201,21 @@ class FramePipe:
                 self.copier.wait(t)
 
     def run(self, src: torch.Tensor):
+        # Nothing in a step waits on the host any more (round 4), so a caller that loops would queue steps without bound
+        # and end up spinning inside the runtime once its hardware queue is full: at most two steps are kept in flight,
+        # the wait for the third-last one polls its event and sleeps in between.
+        self._throttle()
         self.stage_dehaze_histretch(src)
         self.stage_aclahe()
         self.stage_overlap()
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        self._inflight.append(ev)
         return self.work, self.ratio
+
+    def _throttle(self, keep: int = 2):
+        import time
+        while len(self._inflight) >= keep:
+            ev = self._inflight.pop(0)
+            while not ev.query():
+                time.sleep(1e-3)            # two steps are in flight: a millisecond of slack costs nothing
