@@ -641,7 +641,16 @@ class Rig:
             t.join()
 
     def run_steps(self, k):
-        """k steps: every sub-batch thread runs its k passes back to back (no per-step rendezvous between the host threads)"""
+        """k steps: every sub-batch thread runs its k passes back to back (no per-step rendezvous between the host threads).
+        Default since round 4: ONE host thread submits the steps of all sub-batches round robin -- nothing in a step waits on
+        the host any more, so threads would only exist to submit launches (measured: the same frames/s, 0.0035 instead of
+        0.01-0.03 CPU-seconds per step); UWIP_BENCH_ONE_SUBMITTER=0 brings the thread per sub-batch back.  The host-buffer
+        leg keeps its threads: there a sub-batch waits for copy tickets."""
+        if os.environ.get("UWIP_BENCH_ONE_SUBMITTER", "1") == "1":
+            for _ in range(k):
+                for i in range(self.S):
+                    self.pipes[i].run(self.parts[i])
+            return
         def loop(i):
             for _ in range(k):
                 self.pipes[i].run(self.parts[i])
@@ -860,6 +869,7 @@ def main():
             "config": {"name": args.config,
                        "workload": f"full pipe bgdehaze->histretch->aclahe->videostrip-overlap on {W}x{H} uchar3 frames",
                        "frames_per_gpu_per_step": F, "streams_per_gpu": S, "stages": stages,
+                       "host_threads_submitting": 1 if os.environ.get("UWIP_BENCH_ONE_SUBMITTER", "1") == "1" else S,
                        "parallelism": f"frame-batch x{world}", "rank0_placement": placement},
             "check_note": "outputs_identical_across_streams: the sub-batch pipes of a rank hold the same frames, so after the timed "
                           "steps all must hold byte-identical enhanced frames, ACLAHE parameters and overlap ratios (every rank); "
