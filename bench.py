@@ -664,6 +664,12 @@ class Rig:
 
     def run_steps_host(self, k):
         """the same k steps with every frame uploaded from and downloaded to page-locked host memory"""
+        if os.environ.get("UWIP_BENCH_ONE_SUBMITTER_HOST") == "1":          # A/B: one thread waits for the tickets in request order
+            for _ in range(k):
+                for i in range(self.S):
+                    p, (hi, ho) = self.pipes[i], self.bufs[i]
+                    p.run_host(hi, ho, prefetch=hi)
+            return
         def loop(i):
             p, (hi, ho) = self.pipes[i], self.bufs[i]
             for _ in range(k):
