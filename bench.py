@@ -644,8 +644,7 @@ class Rig:
         """k steps: every sub-batch thread runs its k passes back to back (no per-step rendezvous between the host threads).
         Default since round 4: ONE host thread submits the steps of all sub-batches round robin -- nothing in a step waits on
         the host any more, so threads would only exist to submit launches (measured: the same frames/s, 0.0035 instead of
-        0.01-0.03 CPU-seconds per step); UWIP_BENCH_ONE_SUBMITTER=0 brings the thread per sub-batch back.  The host-buffer
-        leg keeps its threads: there a sub-batch waits for copy tickets."""
+        0.01-0.03 CPU-seconds per step); UWIP_BENCH_ONE_SUBMITTER=0 brings the thread per sub-batch back."""
         if os.environ.get("UWIP_BENCH_ONE_SUBMITTER", "1") == "1":
             for _ in range(k):
                 for i in range(self.S):
@@ -664,7 +663,9 @@ class Rig:
 
     def run_steps_host(self, k):
         """the same k steps with every frame uploaded from and downloaded to page-locked host memory"""
-        if os.environ.get("UWIP_BENCH_ONE_SUBMITTER_HOST") == "1":          # A/B: one thread waits for the tickets in request order
+        # one thread here too (it waits for the copy tickets in the order it requested them; measured equal to a thread per
+        # sub-batch: 2893-2914 against 2904-2919 frames/s end to end); UWIP_BENCH_ONE_SUBMITTER=0 brings the threads back
+        if os.environ.get("UWIP_BENCH_ONE_SUBMITTER", "1") == "1":
             for _ in range(k):
                 for i in range(self.S):
                     p, (hi, ho) = self.pipes[i], self.bufs[i]
