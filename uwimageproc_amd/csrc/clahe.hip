@@ -433,11 +433,15 @@ __device__ __forceinline__ void clahe_lut_rows(const int (&h0)[4], int lane, flo
         wv = __builtin_amdgcn_cvt_pk_u8_f32((float)(off + p2) * lutScale, 2, wv);
         return __builtin_amdgcn_cvt_pk_u8_f32((float)(off + p3) * lutScale, 3, wv);
     };
-    const uint32_t w_unclipped = lut_word(h0);
+    uint32_t w_unclipped = 0;
+    bool have_unclipped = false;                 // computed when the first limit that clips nothing asks for it
     for (int c = 0; c < ncl; ++c) {
         const int clip = frame_clip >= 0 ? frame_clip : cl.clip[c];
-        uint32_t w = w_unclipped;
-        if (clip > 0 && clip < m) {                                    // wave-uniform
+        uint32_t w;
+        if (!(clip > 0 && clip < m)) {                                 // wave-uniform
+            if (!have_unclipped) { w_unclipped = lut_word(h0); have_unclipped = true; }
+            w = w_unclipped;
+        } else {
             int h[4] = {h0[0], h0[1], h0[2], h0[3]};
             int excess = 0;
 #pragma unroll
@@ -500,41 +504,52 @@ __global__ __launch_bounds__(256) void k_clahe_lut(const uint32_t *__restrict__ 
 constexpr int BAND_SLOTS = 4;
 constexpr int BAND_TSTRIDE = 128 * BAND_SLOTS + 4;          // words per tile: + 4 = the bank skew between neighbouring tiles
 constexpr int BAND_THREADS = 512;
-template <int CHUNKS>       // 64-unit chunks per image row (1, 2, 4, 8); BAND_THREADS / 64 / CHUNKS waves share a chunk
+// A block may own a PART of the row of tiles (tpb tiles: the 32 tiles of a 32 x 32 grid as two blocks of 16, 33 KB of LDS
+// each, four blocks per CU like the 16 x 16 grid instead of two at 66 KB): units at a part's edge straddle a neighbouring
+// part's tile, whose pixels add zero here.  (Measured and dropped: the same image as 32-bit counters with two slots per bin --
+// 3 instead of 7 vector instructions per pixel, twice the lanes per slot: 16 x 16 grid 48 -> 65 us, 32 x 32 64 -> 62: the
+// kernel is bound by LDS collisions, not by its instruction count.)
+template <int CHUNKS>       // 64-unit chunks per part of an image row (1, 2, 4, 8); BAND_THREADS / 64 / CHUNKS waves share a chunk
 __global__ __launch_bounds__(BAND_THREADS) void k_clahe_band(const uint8_t *__restrict__ src, size_t step, size_t fstride, int rows, int cols,
-                                                             int gx, int tw, uint32_t tw_magic, int th, const int *__restrict__ frame_map, float lutScale,
+                                                             int gx, int tw, uint32_t tw_magic, int th, int tpb, int nparts,
+                                                             const int *__restrict__ frame_map, float lutScale,
                                                              ClipList cl, const int *__restrict__ frame_clip, int rule,
                                                              uint8_t *__restrict__ luts, uint32_t *__restrict__ tile_max, int tiles,
                                                              const int *__restrict__ nf_dev /*optional*/)
 {
     if (nf_dev && (int)blockIdx.y >= *nf_dev) return;
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_band[];      // [gx][BAND_TSTRIDE]
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_band[];      // [tpb][BAND_TSTRIDE]
     struct __attribute__((packed, aligned(1))) U16 { uint32_t x, y, z, w; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ty = blockIdx.x, f = blockIdx.y;
+    const int ty = (int)blockIdx.x / nparts, part = (int)blockIdx.x - ty * nparts, f = blockIdx.y;
+    const int tx0 = part * tpb, ntx = min(tpb, gx - tx0);
+    const int xA = tx0 * tw, xB = min((tx0 + ntx) * tw, cols);          // this part's in-image columns [xA, xB)
     const int fr = frame_map ? frame_map[f] : f;
     const uint8_t *base = src + (size_t)fr * fstride;
-    for (int i = tid; i < gx * BAND_TSTRIDE; i += BAND_THREADS) s_band[i] = 0;
+    for (int i = tid; i < ntx * BAND_TSTRIDE; i += BAND_THREADS) s_band[i] = 0;
     __syncthreads();
     constexpr int WPC = BAND_THREADS / 64 / CHUNKS;          // waves per chunk
     const int chunk = wave / WPC, wrow = wave - chunk * WPC;
-    const int nu = (cols + 15) >> 4;
-    const int u = chunk * 64 + lane;
-    if (u < nu) {
+    const int ua = xA >> 4, ub = (xB + 15) >> 4;             // the 16-byte units (counted from the row start) that touch [xA, xB)
+    const int u = ua + chunk * 64 + lane;
+    if (u < ub && xB > xA) {
         // this lane's unit: pixels [x0, x0 + 16) of every row -- the last unit of a row whose width is not a multiple of 16
         // is loaded ENDING at the last column and its leading bytes, pixels of the previous unit, add zero
         const int x0 = u * 16;
         int xl = x0;
         uint32_t vm = 0xffffu;
         if (x0 + 16 > cols) { xl = cols - 16; vm = (0xffffu << (x0 - xl)) & 0xffffu; }
-        // LDS byte address of the counter image of the tile each of the 16 loaded pixels falls in (+ this lane's slot)
+        // LDS byte address of the counter image of the tile each of the 16 loaded pixels falls in (+ this lane's slot);
+        // pixels left or right of this part's columns belong to another block: their mask bit goes
         uint32_t cbase[16];
         const uint32_t slot = (uint32_t)(lane & (BAND_SLOTS - 1)) * 4u;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int x = xl + k;
             const int tx = (int)__umulhi((unsigned)x, tw_magic);       // x / tw: tw_magic = floor(2^32 / tw) + 1, exact while x * tw < 2^32
-            cbase[k] = (uint32_t)tx * (BAND_TSTRIDE * 4u) + slot;
+            const bool mine = x >= xA && x < xB;
+            if (!mine) vm &= ~(1u << k);
+            cbase[k] = (uint32_t)(mine ? tx - tx0 : 0) * (BAND_TSTRIDE * 4u) + slot;
         }
         const uint8_t *colp = base + xl;
         constexpr int U = 4;
@@ -558,24 +573,26 @@ __global__ __launch_bounds__(BAND_THREADS) void k_clahe_band(const uint8_t *__re
             }
         }
     }
-    // reflected padding columns [cols, gx * tw): a few per row
-    const int npad = gx * tw - cols;
-    for (int i = tid; i < npad * th; i += BAND_THREADS) {
-        const int jr = i / npad, x = cols + (i - jr * npad);
-        const uint32_t v = base[(size_t)reflect101(ty * th + jr, rows) * step + reflect101(x, cols)];
-        const int tx = x / tw;
-        atomicAdd(&s_band[tx * BAND_TSTRIDE + (v >> 1) * BAND_SLOTS + (tid & (BAND_SLOTS - 1))], (v & 1u) ? 65536u : 1u);
+    // reflected padding columns [cols, gx * tw): a few per row, the last part's
+    if (part == nparts - 1) {
+        const int npad = gx * tw - cols;
+        for (int i = tid; i < npad * th; i += BAND_THREADS) {
+            const int jr = i / npad, x = cols + (i - jr * npad);
+            const uint32_t v = base[(size_t)reflect101(ty * th + jr, rows) * step + reflect101(x, cols)];
+            const int tx = x / tw - tx0;
+            atomicAdd(&s_band[tx * BAND_TSTRIDE + (v >> 1) * BAND_SLOTS + (tid & (BAND_SLOTS - 1))], (v & 1u) ? 65536u : 1u);
+        }
     }
     __syncthreads();
     // histograms -> LUT rows: a wave per tile, lane l owns bins 4l .. 4l+3 = pairs 2l, 2l + 1
-    for (int tx = wave; tx < gx; tx += BAND_THREADS / 64) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(&s_band[tx * BAND_TSTRIDE + (2 * lane) * BAND_SLOTS]);
-        const uint4 b = *reinterpret_cast<const uint4 *>(&s_band[tx * BAND_TSTRIDE + (2 * lane + 1) * BAND_SLOTS]);
+    for (int tl = wave; tl < ntx; tl += BAND_THREADS / 64) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(&s_band[tl * BAND_TSTRIDE + (2 * lane) * BAND_SLOTS]);
+        const uint4 b = *reinterpret_cast<const uint4 *>(&s_band[tl * BAND_TSTRIDE + (2 * lane + 1) * BAND_SLOTS]);
         static_assert(BAND_SLOTS == 4, "one 16-byte read per pair of bins");
         // a tile holds < 65536 pixels (host: checked), so the packed halves can be added as whole words
         const uint32_t sa = a.x + a.y + a.z + a.w, sb = b.x + b.y + b.z + b.w;
         const int h0[4] = {(int)(sa & 0xffffu), (int)(sa >> 16), (int)(sb & 0xffffu), (int)(sb >> 16)};
-        const int t = ty * gx + tx;
+        const int t = ty * gx + tx0 + tl;
         clahe_lut_rows(h0, lane, lutScale, cl, frame_clip ? frame_clip[f] : -1, rule, luts + (((size_t)f * tiles + t) * cl.n) * 256,
                        tile_max ? tile_max + (size_t)f * tiles + t : nullptr);
     }
@@ -1075,26 +1092,34 @@ bool band_ok(const uwip_batch_u8 *src, const ClaheGeom &g)
     static const bool off = [] { const char *e = std::getenv("UWIP_CLAHE_BAND"); return e && *e == '0'; }();      // A/B
     const bool bp = (long long)g.tw * g.th >= TH_BP_MIN && (g.tw & 15) == 0 && g.tw * g.gx == g.cols && g.tw < (1 << 17) &&
                     ((reinterpret_cast<uintptr_t>(src->data) | src->step | src->frame_stride) & 15u) == 0;
-    return !off && !bp && g.cols >= 16 && g.cols <= 8192 && (long long)g.tw * g.th < 65536 &&
-           (size_t)g.gx * BAND_TSTRIDE * 4 <= 96 * 1024 && g.gy <= 65535;
+    return !off && !bp && g.cols >= 16 && g.cols <= 8192 && (long long)g.tw * g.th < 65536 && g.gy <= 4096;
 }
 
 int launch_band(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g, const int *d_frame_map, int nf, const ClipList &cl,
                 const int *d_frame_clip, int rule, uint8_t *d_luts, uint32_t *d_tile_max, const int *d_nf = nullptr)
 {
-    const int nu = (g.cols + 15) >> 4;
+    // tiles per block: as many as fill one 64-unit chunk (1024 columns: every lane of the block's eight waves busy), at most
+    // 16 (33 KB of LDS: four blocks per CU).  Measured per 64 frames of 1080p (tools/tilehist_only.py, UWIP_BAND_TPB): 16 x 16
+    // grid (121-pixel tiles) 8 tiles per block 43.9 us, 16 (the whole row) 48.5; 32 x 32 grid (61-pixel tiles) 16 per block
+    // 63.1, 32 (the whole row, 66 KB) 66.5, 8 (half the lanes idle) 99.5.
+    static const int env_tpb = [] { const char *e = std::getenv("UWIP_BAND_TPB"); return e && *e ? std::atoi(e) : 0; }();
+    int tpb = std::min(g.gx, std::min(16, std::max(1, 1024 / g.tw)));
+    if (env_tpb > 0) tpb = std::min(env_tpb, g.gx);
+    const int nparts = (g.gx + tpb - 1) / tpb;
+    const int part_cols = std::min(tpb * g.tw, g.cols);
+    const int nu = (part_cols + 15) / 16 + 1;                          // a part's columns need not start on a unit boundary
     const int chunks = nu <= 64 ? 1 : (nu <= 128 ? 2 : (nu <= 256 ? 4 : 8));
-    const size_t lds = (size_t)g.gx * BAND_TSTRIDE * 4;
+    const size_t lds = (size_t)tpb * BAND_TSTRIDE * 4;
     const uint32_t magic = (uint32_t)(4294967296ull / (uint64_t)g.tw) + 1u;
     const int tiles = g.gx * g.gy;
-    dim3 grid((unsigned)g.gy, (unsigned)nf);
+    dim3 grid((unsigned)(g.gy * nparts), (unsigned)nf);
     uwip_kscope ks(ctx, "k_clahe_band");
 #define UWIP_BAND(C)                                                                                                                   \
     do {                                                                                                                               \
         int rc_l = uwip_lds_optin(ctx, "k_clahe_band" #C, (const void *)k_clahe_band<C>, lds);                                          \
         if (rc_l) return rc_l;                                                                                                         \
         k_clahe_band<C><<<grid, BAND_THREADS, lds, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, g.rows, g.cols, \
-                                                               g.gx, g.tw, magic, g.th, d_frame_map, g.lutScale, cl, d_frame_clip, rule, \
+                                                               g.gx, g.tw, magic, g.th, tpb, nparts, d_frame_map, g.lutScale, cl, d_frame_clip, rule, \
                                                                d_luts, d_tile_max, tiles, d_nf);                                        \
     } while (0)
     switch (chunks) {
