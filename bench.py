@@ -311,13 +311,22 @@ def stage_of(kernel):
 
 def pmc_entry(kernel, rows, cols):
     """Committed counter digest of the same command (tools/pmc_digest.py over separate rocprofv3 --pmc passes; the
-    counters cannot be read inside this process).  None when no matching profile is committed."""
+    counters cannot be read inside this process).  The passes are taken at 1920x1080; for another frame size the
+    per-frame counters of that digest are scaled by the pixel ratio (these kernels do a fixed amount of work per pixel)
+    and the entry says so.  None when no matching profile is committed."""
     for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             e = d.get(f"{cols}x{rows}", {}).get(kernel)
             if e is not None:
                 return e
+            e = d.get("1920x1080", {}).get(kernel)
+            if e is not None:
+                k = (rows * cols) / (1080.0 * 1920.0)
+                s = {key: (val * k if isinstance(val, (int, float)) and key.endswith("_per_frame") or key.endswith("per_frame_fetch_as_reported") else val)
+                     for key, val in e.items()}
+                s["scaled_from"] = f"1920x1080 counters x {k:.3f} (pixel ratio)"
+                return s
         except Exception:
             pass
     return None
