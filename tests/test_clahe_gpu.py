@@ -77,6 +77,32 @@ def test_tilehist_general_slot_keyed_form(ctx, orc, shape, grid):
         assert np.array_equal(c.luts(view).cpu().numpy()[0], orc.clahe(frames[0], 2.5, grid[0], grid[1], 0, want_luts=True)[1])
 
 
+@pytest.mark.parametrize("shape,grid", [((40, 20), (32, 32)), ((33, 32), (32, 32)), ((64, 27), (32, 8)), ((543, 1915), (49, 5)),
+                                        ((200, 1915), (49, 3)), ((97, 1000), (62, 4)), ((97, 630), (33, 3))])
+def test_band_geometries_one_pixel_tiles_and_padding_over_several_parts(ctx, orc, shape, grid):
+    """ADVICE r4 (k_clahe_band): tiles ONE pixel wide (16 <= cols <= 32 under the 32 x 32 grid every aclahe sweep runs: the
+    multiply-high division does not exist for tw = 1 -> the separate kernels), and reflect-101 padding columns that cover
+    more tiles than the last part of a row of tiles owns (cols = 1915, gx = 49 -> tw = 40, 16 tiles per block, last part =
+    tile 48 alone, padding over tiles 47 and 48: every part now counts the padding of its own tiles).  LUTs, output and --
+    for the first two -- the whole sweep table's histograms against the oracle."""
+    rows, cols = shape
+    rng = np.random.default_rng(rows * 11 + cols)
+    frames = rng.integers(0, 256, (2, rows, cols), dtype=np.uint8)
+    frames[1] = _v(orc, 11, rows, cols)
+    c = aclahe.CLAHE(ctx, 3.0, grid)
+    t = _dev(frames)
+    luts = c.luts(t).cpu().numpy()
+    out = c.apply(t).cpu().numpy()
+    for f in range(2):
+        exp, exp_luts = orc.clahe(frames[f], 3.0, grid[0], grid[1], 0, want_luts=True)
+        assert np.array_equal(luts[f], exp_luts), f
+        assert np.array_equal(out[f], exp), f
+    if cols <= 32:
+        tab = aclahe.sweep(ctx, t).cpu().numpy()
+        for f in range(2):
+            assert np.abs(tab[f] - orc.sweep(frames[f])).max() <= 1e-5, f
+
+
 @pytest.mark.parametrize("kind", ["random", "constant", "two_level", "ramp"])
 def test_clahe_adversarial(ctx, orc, kind):
     src = np.ascontiguousarray(synth.adversarial(kind, 100, 140)[..., 0])

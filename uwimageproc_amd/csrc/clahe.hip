@@ -573,11 +573,14 @@ __global__ __launch_bounds__(BAND_THREADS) void k_clahe_band(const uint8_t *__re
             }
         }
     }
-    // reflected padding columns [cols, gx * tw): a few per row, the last part's
-    if (part == nparts - 1) {
-        const int npad = gx * tw - cols;
+    // reflected padding columns [cols, gx * tw): every part counts those that fall into ITS tiles (with a grid that is not a
+    // power of two the padding can cover more tiles than the last part owns: cols = 1915, gx = 49 -> tw = 40, padding over
+    // tiles 47 and 48, the last part holding tile 48 alone)
+    {
+        const int pa = max(cols, tx0 * tw), pb = (tx0 + ntx) * tw;
+        const int npad = pb - pa;
         for (int i = tid; i < npad * th; i += BAND_THREADS) {
-            const int jr = i / npad, x = cols + (i - jr * npad);
+            const int jr = i / npad, x = pa + (i - jr * npad);
             const uint32_t v = base[(size_t)reflect101(ty * th + jr, rows) * step + reflect101(x, cols)];
             const int tx = x / tw - tx0;
             atomicAdd(&s_band[tx * BAND_TSTRIDE + (v >> 1) * BAND_SLOTS + (tid & (BAND_SLOTS - 1))], (v & 1u) ? 65536u : 1u);
@@ -1092,7 +1095,8 @@ bool band_ok(const uwip_batch_u8 *src, const ClaheGeom &g)
     static const bool off = [] { const char *e = std::getenv("UWIP_CLAHE_BAND"); return e && *e == '0'; }();      // A/B
     const bool bp = (long long)g.tw * g.th >= TH_BP_MIN && (g.tw & 15) == 0 && g.tw * g.gx == g.cols && g.tw < (1 << 17) &&
                     ((reinterpret_cast<uintptr_t>(src->data) | src->step | src->frame_stride) & 15u) == 0;
-    return !off && !bp && g.cols >= 16 && g.cols <= 8192 && (long long)g.tw * g.th < 65536 && g.gy <= 4096;
+    // tw >= 2: the column -> tile division is a multiply-high by floor(2^32 / tw) + 1, which does not exist for tw = 1
+    return !off && !bp && g.tw >= 2 && g.cols >= 16 && g.cols <= 8192 && (long long)g.tw * g.th < 65536 && g.gy <= 4096;
 }
 
 int launch_band(uwip_ctx *ctx, const uwip_batch_u8 *src, const ClaheGeom &g, const int *d_frame_map, int nf, const ClipList &cl,

@@ -149,7 +149,12 @@ struct SolveRow<NP, true> {
 // scanning its own 256; the scans meet in LDS -- a window that straddles the two halves adds the left wave's row total --
 // behind one workgroup barrier per phase.  Useful columns per lane-column rise from 176 / 256 to 432 / 512: at 1920
 // columns 5 strips x 512 instead of 11 x 256 (-9 % of all work), at 3840 columns 9 x 512 instead of 22 x 256 (-18 %).
-template <int NP, bool VEC, bool PU8, bool C3, int NW>
+// PTAB (PU8 only): p through a 256-entry float64 table per plane in LDS (4 KB at NP = 2) -- or, PTAB = false, computed per
+// sample as max(1 - (m - mn) * c_ip, tmin) with c_ip = 1 / ((mx - mn) B_ip): a conversion, an fma and a max instead of an
+// LDS gather, within 2 ulp of the table's two divisions (the filter is compared at 1e-9), and 25.6 instead of 29.7 KB of
+// LDS per wave: four solve waves then leave a CU 56 KB, room for one 52 KB block of k_clahe_sweep (with the table they
+// left 41 KB and the VALU-bound sweep could not join the latency-bound solve on a CU; DESIGN.md section 5, co-residency).
+template <int NP, bool VEC, bool PU8, bool C3, int NW, bool PTAB = true>
 __global__ __launch_bounds__(64 * NW) void k_gf_ws_solve(const uint8_t *__restrict__ guide, size_t step, size_t fs,
                                                     const int *__restrict__ gnorm, int gnorm_stride,
                                                     const double *__restrict__ P /*[F][NP][H][W]*/,
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(64 * NW) void k_gf_ws_solve(const uint8_t *__restri
     __shared__ double2 s_d2[NW * NP * 2 * 4 * 64];
     __shared__ uint32_t s_tu[NW][12];          // row totals of a wave's nine integer planes
     __shared__ double s_td[NW][NP * 4];        // ... and of its 4 NP float64 planes
-    __shared__ double s_ptab[PU8 ? NP * 256 : 1];
+    __shared__ double s_ptab[PU8 && PTAB ? NP * 256 : 1];
     unsigned bx, by, bz;
     if (!xcd_decode(nb.x, nb.y, nb.z, bx, by, bz)) return;
     StripGeom sg;
@@ -183,12 +188,21 @@ __global__ __launch_bounds__(64 * NW) void k_gf_ws_solve(const uint8_t *__restri
     double p_out = 0.0;         // PU8: p where the window leaves the image
     bool cin[4] = {true, true, true, true};
     const int ip0 = (zg - f * fdiv) * NP;     // first of this block's p planes inside the frame
+    double pc[NP];              // !PTAB: c_ip
+#pragma unroll
+    for (int ip = 0; ip < NP; ++ip) pc[ip] = 0.0;
     if (PU8) {
-        for (int idx = (int)threadIdx.x; idx < NP * 256; idx += 64 * NW) {
-            const int ip = idx >> 8, v = idx & 255;
-            const double B = pu8.sc[(size_t)f * pu8.sc_stride + pu8.b_off + ip0 + ip];
-            const double q = ((double)(v - mn) / (double)(mx - mn)) / B;
-            s_ptab[idx] = fmax(1.0 - q, pu8.tmin);
+        if constexpr (PTAB) {
+            for (int idx = (int)threadIdx.x; idx < NP * 256; idx += 64 * NW) {
+                const int ip = idx >> 8, v = idx & 255;
+                const double B = pu8.sc[(size_t)f * pu8.sc_stride + pu8.b_off + ip0 + ip];
+                const double q = ((double)(v - mn) / (double)(mx - mn)) / B;
+                s_ptab[idx] = fmax(1.0 - q, pu8.tmin);
+            }
+        } else {
+#pragma unroll
+            for (int ip = 0; ip < NP; ++ip)
+                pc[ip] = 1.0 / ((double)(mx - mn) * pu8.sc[(size_t)f * pu8.sc_stride + pu8.b_off + ip0 + ip]);
         }
         p_out = fmax(1.0 - 0.0, pu8.tmin);
 #pragma unroll
@@ -303,7 +317,11 @@ __global__ __launch_bounds__(64 * NW) void k_gf_ws_solve(const uint8_t *__restri
 #pragma unroll
             for (int ip = 0; ip < NP; ++ip) {
                 double pv;
-                if constexpr (PU8) pv = (rin && cin[j]) ? s_ptab[ip * 256 + ((R.m[ip] >> (8 * j)) & 255u)] : p_out;
+                if constexpr (PU8 && PTAB) pv = (rin && cin[j]) ? s_ptab[ip * 256 + ((R.m[ip] >> (8 * j)) & 255u)] : p_out;
+                else if constexpr (PU8) {
+                    const double pt = fmax(fma(-(double)((int)((R.m[ip] >> (8 * j)) & 255u) - mn), pc[ip], 1.0), pu8.tmin);
+                    pv = (rin && cin[j]) ? pt : p_out;
+                }
                 else pv = R.p[ip][j];
                 pv *= (ADD ? pm : -pm);
                 pf[j][ip][0] += pv; pf[j][ip][1] += da * pv; pf[j][ip][2] += db * pv; pf[j][ip][3] += dc * pv;
@@ -733,6 +751,11 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
     UWIP_REQUIRE(ctx, (uint64_t)uwip_cdiv(W, 256 - 2 * r) * 16 * F * np < (1ull << 31) && (uint64_t)uwip_cdiv(W, 256 - 2 * r) * (2 * r + 1) * F * np < (1ull << 31), "too many blocks for one launch");
     UWIP_REQUIRE(ctx, (uint64_t)256 * (2 * r + 1) * 65025ull < (1ull << 32), "window too large for the exact integer guide sums");
     const int D = 2 * r + 1;
+    // UWIP_DIAG_GF_ONLY=solve | final (read at every call): launch only that kernel of the pair, the other one's output being
+    // whatever the workspace holds from an earlier complete call.  A MEASUREMENT hook (tools/corun_matrix.py runs the two
+    // kernels against each other and against the sweep on separate streams); results of such a call are meaningless.
+    int diag_only = 0;
+    if (const char *e = getenv("UWIP_DIAG_GF_ONLY")) diag_only = e[0] == 's' ? 1 : (e[0] == 'f' ? 2 : 0);
     // four adjacent columns of a lane are one aligned vector access when everything is a multiple of 4
     const bool vec = (W % 4 == 0) && (r % 4 == 0) && (step % 4 == 0) && (fs % 4 == 0) && (((uintptr_t)guide) % 4 == 0) &&
                      (((uintptr_t)P | (uintptr_t)Q | (uintptr_t)AB) % 16 == 0);
@@ -795,8 +818,19 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
 #define UWIP_GF_SOLVE(NPV, VECV, PU8V, C3V, NWV)                                                                                     \
     k_gf_ws_solve<NPV, VECV, PU8V, C3V, NWV><<<grid, 64 * NWV, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, eps, \
                                                                                TSs, rpc, fdiv, nb, pa)
+#define UWIP_GF_SOLVE_NT(NPV, C3V, NWV)                                                                                              \
+    k_gf_ws_solve<NPV, true, true, C3V, NWV, false><<<grid, 64 * NWV, 0, ctx->stream>>>(guide, step, fs, gnorm, gstride, P, AB, H, W, r, \
+                                                                                      eps, TSs, rpc, fdiv, nb, pa)
         const bool c3 = nw == 1 && TSs <= 192;
-        if (pu8 && knp == 1) {
+        // the 8-bit p source without its LDS table (the default; UWIP_GF_PTAB=1 keeps the table: A/B)
+        static const bool ptab = [] { const char *e = getenv("UWIP_GF_PTAB"); return e && atoi(e) > 0; }();
+        if (diag_only == 2) {
+            // diagnostic: the second kernel alone (tools/corun_matrix.py)
+        } else if (pu8 && knp == 1 && !ptab) {
+            if (nw == 2) UWIP_GF_SOLVE_NT(1, false, 2); else if (c3) UWIP_GF_SOLVE_NT(1, true, 1); else UWIP_GF_SOLVE_NT(1, false, 1);
+        } else if (pu8 && !ptab) {
+            if (nw == 2) UWIP_GF_SOLVE_NT(2, false, 2); else if (c3) UWIP_GF_SOLVE_NT(2, true, 1); else UWIP_GF_SOLVE_NT(2, false, 1);
+        } else if (pu8 && knp == 1) {
             if (nw == 2) UWIP_GF_SOLVE(1, true, true, false, 2); else if (c3) UWIP_GF_SOLVE(1, true, true, true, 1); else UWIP_GF_SOLVE(1, true, true, false, 1);
         } else if (pu8) {
             if (nw == 2) UWIP_GF_SOLVE(2, true, true, false, 2); else if (c3) UWIP_GF_SOLVE(2, true, true, true, 1); else UWIP_GF_SOLVE(2, true, true, false, 1);
@@ -807,6 +841,7 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
             if (vec) { if (nw == 2) UWIP_GF_SOLVE(1, true, false, false, 2); else if (c3) UWIP_GF_SOLVE(1, true, false, true, 1); else UWIP_GF_SOLVE(1, true, false, false, 1); }
             else { if (c3) UWIP_GF_SOLVE(1, false, false, true, 1); else UWIP_GF_SOLVE(1, false, false, false, 1); }
         }
+#undef UWIP_GF_SOLVE_NT
 #undef UWIP_GF_SOLVE
     }
     {
@@ -845,7 +880,9 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
         }
 #define UWIP_GF_FINAL(VECV, RECV, NWV) \
     k_gf_ws_final<VECV, RECV, NWV><<<grid, 64 * NWV, 0, ctx->stream>>>(AB, guide, step, fs, gnorm, gstride, np, Q, H, W, r, TSf, rpc, spw, nb, ra)
-        if (rec) { if (nwf == 4) UWIP_GF_FINAL(true, true, 4); else if (nwf == 2) UWIP_GF_FINAL(true, true, 2); else UWIP_GF_FINAL(true, true, 1); }
+        if (diag_only == 1) {
+            // diagnostic: the first kernel alone
+        } else if (rec) { if (nwf == 4) UWIP_GF_FINAL(true, true, 4); else if (nwf == 2) UWIP_GF_FINAL(true, true, 2); else UWIP_GF_FINAL(true, true, 1); }
         else if (vec) { if (nwf == 4) UWIP_GF_FINAL(true, false, 4); else if (nwf == 2) UWIP_GF_FINAL(true, false, 2); else UWIP_GF_FINAL(true, false, 1); }
         else UWIP_GF_FINAL(false, false, 1);
 #undef UWIP_GF_FINAL
