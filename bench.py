@@ -31,6 +31,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# The library's defaults are the reference's rules (uwip.h).  The bench opts into ONE deviation and says so in `config.rules`:
+# UWIP_DEHAZE_GUARD_S -- as written, one 0/0 in the exposure map S (BGDehaze.py:83) turns a whole frame into NaN -> black
+# (SURVEY B-11), and a black frame is a trivial workload for every stage after it: a synthetic frame that happens to hit it
+# would make the timed step cheaper, not dearer.  The overlap rule is the reference's (>= 4 good matches).
+GUARD_S = True
 
 
 def parse():
@@ -60,6 +65,10 @@ def parse():
                     help="skip the upload/download-inclusive variant (timed on every rank after the main region)")
     ap.add_argument("--no-4k", dest="fourk", action="store_false",
                     help="skip the short 3840x2160 leg of the default line (configs 3 / 5: 6 steps + a 2 s paced 4K@60 stream)")
+    ap.add_argument("--scenes", type=int, default=3,
+                    help="synthetic scenes (different seed0) the timed region is repeated on after the headline scene: the cost of "
+                         "the sweep depends on how many clip limits still clip, i.e. on the scene; the line reports each scene's "
+                         "frames/s and sweep time and their min / median / max (1 = the headline scene only)")
     ap.add_argument("--no-pin", dest="pin", action="store_false",
                     help="do not restrict the rank to the CPUs of its GPU's NUMA node")
     a = ap.parse_args()
@@ -91,7 +100,7 @@ def paced_stream(args, dev_index, dev, H, W):
     frames = synth_frames(max(B, 8), H, W, 4321)
     st = torch.cuda.Stream(dev)
     with torch.cuda.stream(st):
-        pipe = FramePipe(dev_index, B, H, W)
+        pipe = FramePipe(dev_index, B, H, W, guard_s=GUARD_S)
     h_in, h_out = pipe.host_buffers()
     for w in range(2):                                   # warm-up: workspaces, tables
         h_in[...] = frames[:B]
@@ -150,20 +159,36 @@ def cpu_baseline(H, W, spot=None):
         build = "gcc -O3 -march=native -ffp-contract=off (built on this host)"
     except Exception:
         orc = _oracle.load()
-    # the ONE product function inside the CPU baseline: the parameter choice (MINPACK / spline restatement, pure host code,
-    # 0.5 ms of ~2.9 s per frame) -- the oracle has no C form of it (its checker is scipy, tests/_knee_mirror.py)
-    select = uwip_lib().uwip_aclahe_select
+    # The parameter choice inside the CPU baseline and the spot check: the scipy mirror of the reference's own calls
+    # (tests/_knee_mirror.py: curve_fit / splrep / splev as functions.py:49-93 makes them) when scipy imports -- a checker
+    # independent of the product's MINPACK restatement; only without scipy the product's host function uwip_aclahe_select
+    # (0.5 ms of ~2.9 s per frame) stands in, and `select_kind` says which it was.
+    _sel_c = uwip_lib().uwip_aclahe_select
+    try:
+        import _knee_mirror
+        import scipy.optimize  # noqa: F401
+        select_kind = "scipy mirror of functions.py:49-93 (tests/_knee_mirror.py)"
+
+        def select(tab):
+            return _knee_mirror.select_parameters(np.asarray(tab, np.float32).reshape(5, 51))
+    except Exception:
+        select_kind = "uwip_aclahe_select (product host function: scipy not importable here)"
+
+        def select(tab):
+            bs, cl = C.c_int32(0), C.c_int32(0)
+            t = np.ascontiguousarray(tab, np.float32)
+            _sel_c(t.ctypes.data_as(C.POINTER(C.c_float)), 1, C.byref(bs), C.byref(cl), None)
+            return bs.value, cl.value
 
     def one_frame(idx, timing=None):
         img = synth.uw_stream_motion(idx, 2, H, W)
         t = [time.perf_counter()]
-        out, _ = orc.dehaze(img[1], 15, full=True, guard_s=True); t.append(time.perf_counter())
+        out, _ = orc.dehaze(img[1], 15, full=True, guard_s=GUARD_S); t.append(time.perf_counter())
         st, _ = orc.histretch(out, "RGB")
         v = orc.bgr_to_v(st)
         tab = np.ascontiguousarray(orc.sweep(orc.gaussian3(v)), np.float32); t.append(time.perf_counter())
-        bs, cl = C.c_int32(0), C.c_int32(0)
-        select(tab.ctypes.data_as(C.POINTER(C.c_float)), 1, C.byref(bs), C.byref(cl), None); t.append(time.perf_counter())
-        fin = orc.hsv_replace_v(st, orc.clahe(v, float(cl.value), bs.value, bs.value)); t.append(time.perf_counter())
+        bs, cl = select(tab); t.append(time.perf_counter())
+        fin = orc.hsv_replace_v(st, orc.clahe(v, float(cl), bs, bs)); t.append(time.perf_counter())
         # overlap against the predecessor: the key frame's features are cached (kframe->new_img), so one detect+describe,
         # one match + homography + overlapArea per frame
         g1 = orc.resize_gray(fin)
@@ -209,11 +234,10 @@ def cpu_baseline(H, W, spot=None):
         walls.append(time.perf_counter() - t1)
     wall = min(walls)
     return {"value": n / wall, "unit": "frames/s", "cores": n, "cores_visible": cores, "cgroup_cpu_quota": quota, "kind": "port",
-            "spot_check_vs_oracle": check,
+            "spot_check_vs_oracle": check, "parameter_choice": select_kind,
             "sample": f"{n} frames of {W}x{H}, one per host thread ({cores} CPUs in the affinity mask, cgroup quota "
                       f"{quota if quota else 'none'}), whole pipe in C ({build}), best of two passes; single thread: 1 frame; "
-                      "the ACLAHE parameter choice inside it is the product's own host function uwip_aclahe_select "
-                      "(0.5 ms per frame; the oracle holds no C form of it)",
+                      f"the ACLAHE parameter choice inside it: {select_kind}",
             "single_thread": {"value": 1.0 / single, "unit": "frames/s", "cores": 1, "seconds_per_frame": single, "parts": parts},
             "all_cores_wall_s": wall, "all_cores_walls_s": walls, "total_cpu_baseline_s": time.perf_counter() - t0}
 
@@ -240,7 +264,7 @@ def spot_capture(rig, dev_index):
     cap = {"frames": rig.parts[0][:n].cpu().numpy().copy(), "out": p.work[:n].cpu().numpy().copy(), "params": list(p.params[:n]),
            "ratio": p.ratio[:n].cpu().numpy().copy(), "vw": p.vw, "vh": p.vh, "seed": p.seed}
     with torch.cuda.stream(torch.cuda.Stream(torch.device("cuda", dev_index))):
-        probe = FramePipe(dev_index, n, rig.H, rig.W)
+        probe = FramePipe(dev_index, n, rig.H, rig.W, guard_s=GUARD_S)
         probe.stage_dehaze(rig.parts[0][:n])
         probe.ctx.sync()
         cap["dehazed"] = probe.work.cpu().numpy().copy()
@@ -252,16 +276,15 @@ def spot_check_vs_oracle(orc, select, cap):
     """One frame of sub-batch 0 of the timed run against the oracle chain (the checker; never the thing measured)."""
     import ctypes as C
     f = len(cap["frames"]) - 1
-    o, _ = orc.dehaze(cap["frames"][f], 15, full=True, guard_s=True)
+    o, _ = orc.dehaze(cap["frames"][f], 15, full=True, guard_s=GUARD_S)
     d = np.abs(cap["dehazed"][f].astype(np.int16) - o.astype(np.int16))
     res = {"frame_of_sub_batch_0": f, "dehaze_max_abs_diff_levels": int(d.max()), "dehaze_frac_bytes_differing": float((d != 0).mean())}
     st, _ = orc.histretch(cap["dehazed"][f], "RGB")
     v = orc.bgr_to_v(st)
     tab = np.ascontiguousarray(orc.sweep(orc.gaussian3(v)), np.float32)
-    bs, cl = C.c_int32(0), C.c_int32(0)
-    select(tab.ctypes.data_as(C.POINTER(C.c_float)), 1, C.byref(bs), C.byref(cl), None)
+    bs, cl = select(tab)
     res["params_device"] = [int(x) for x in cap["params"][f]]
-    res["params_from_oracle_table"] = [bs.value, cl.value]
+    res["params_from_oracle_table"] = [int(bs), int(cl)]
     res["params_equal"] = res["params_device"] == res["params_from_oracle_table"]
     b_, c_ = cap["params"][f]
     e = orc.hsv_replace_v(st, orc.clahe(v, float(c_), int(b_), int(b_)))
@@ -309,16 +332,29 @@ def stage_of(kernel):
     return "bgdehaze"
 
 
+def pmc_provenance(name, d):
+    """which committed digest a replayed counter figure comes from: file, sha256, and -- written into it by
+    tools/pmc_digest.py -- the tree it was taken from (git HEAD + dirty flag) and when"""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", name)
+    meta = d.get("_meta", {}) if isinstance(d, dict) else {}
+    return {"file": f"profiles/{name}", "sha256_16": hashlib.sha256(open(path, "rb").read()).hexdigest()[:16],
+            "mtime": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime(os.path.getmtime(path))),
+            "git_head_at_collection": meta.get("git_head"), "tree_dirty_at_collection": meta.get("dirty"), "collected": meta.get("collected")}
+
+
 def pmc_entry(kernel, rows, cols):
     """Committed counter digest of the same command (tools/pmc_digest.py over separate rocprofv3 --pmc passes; the
     counters cannot be read inside this process).  The passes are taken at 1920x1080; for another frame size the
     per-frame counters of that digest are scaled by the pixel ratio (these kernels do a fixed amount of work per pixel)
     and the entry says so.  None when no matching profile is committed."""
-    for name in ("r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
+    for name in ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json", "r02_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             e = d.get(f"{cols}x{rows}", {}).get(kernel)
             if e is not None:
+                e = dict(e)
+                e["digest"] = pmc_provenance(name, d)
                 return e
             e = d.get("1920x1080", {}).get(kernel)
             if e is not None:
@@ -326,6 +362,7 @@ def pmc_entry(kernel, rows, cols):
                 s = {key: (val * k if isinstance(val, (int, float)) and key.endswith("_per_frame") or key.endswith("per_frame_fetch_as_reported") else val)
                      for key, val in e.items()}
                 s["scaled_from"] = f"1920x1080 counters x {k:.3f} (pixel ratio)"
+                s["digest"] = pmc_provenance(name, d)
                 return s
         except Exception:
             pass
@@ -366,7 +403,9 @@ def matcher_report(ctx, dev, pairs=64):
            "avg_launch_ms": avg, "achieved": tops, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": tops / I8_MFMA_PEAK_TOPS,
            "bound": "mfma"}
     try:                                                     # MFMA counters of the committed rocprofv3 --pmc pass of tools/matcher_only.py
-        out["mfma_counters"] = json.load(open(os.path.join(ROOT, "profiles", "r04_matcher_pmc.json")))
+        mp = "r05_matcher_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_matcher_pmc.json")) else "r04_matcher_pmc.json"
+        out["mfma_counters"] = json.load(open(os.path.join(ROOT, "profiles", mp)))
+        out["mfma_counters_digest"] = pmc_provenance(mp, out["mfma_counters"])
     except Exception:
         out["mfma_counters"] = None
     return out
@@ -429,6 +468,7 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
                 "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else traffic / per_launch,
                 "traffic_source": None if e is None else "committed rocprofv3 --pmc passes of the same command (profiles/*_pmc.json: "
                                   "2 x FETCH_SIZE + WRITE_SIZE per launch), not re-measured in this run",
+                "traffic_digest": None if e is None else e.get("digest"),
                 "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": per_launch}
 
     # (1) the kernel with the largest share of the step
@@ -623,18 +663,41 @@ class Rig:
         Fs = self.Fs
         # one sub-batch worth of DISTINCT consecutive frames of the synthetic stream (seed = 1234 + index), the
         # same ones for every sub-batch: every launch works on Fs different images
-        distinct = min(Fs, 64)
-        base = synth_frames(distinct, H, W, seed0)
-        one = np.concatenate([base] * ((Fs + distinct - 1) // distinct), axis=0)[:Fs]
-        self.src = torch.from_numpy(np.concatenate([one] * S, axis=0)).to(dev)
-        torch.cuda.synchronize()
+        self.dev = dev
+        self.src = torch.empty((F, H, W, 3), dtype=torch.uint8, device=dev)
+        self.load_scene(seed0)
         self.copier = Copier(dev_index)
         self.pipes = []
         for i in range(S):
             with torch.cuda.stream(torch.cuda.Stream(dev)):
-                self.pipes.append(FramePipe(dev_index, Fs, H, W, copier=self.copier))
+                self.pipes.append(FramePipe(dev_index, Fs, H, W, copier=self.copier, guard_s=GUARD_S))
         self.parts = [self.src[i * Fs:(i + 1) * Fs] for i in range(S)]
         self.bufs = None
+
+    def load_scene(self, seed0):
+        """(re)fill the resident input frames with `seed0`'s scene (in place: the sub-batch views stay valid)"""
+        Fs, S = self.Fs, self.S
+        distinct = min(Fs, 64)
+        base = synth_frames(distinct, self.H, self.W, seed0)
+        one = torch.from_numpy(np.concatenate([base] * ((Fs + distinct - 1) // distinct), axis=0)[:Fs]).to(self.dev)
+        torch.cuda.synchronize()
+        for i in range(S):
+            self.src[i * Fs:(i + 1) * Fs].copy_(one)
+        torch.cuda.synchronize()
+        self.seed0 = seed0
+        for p in getattr(self, "pipes", []):
+            p.have_prev = False                  # a new video: no key frame carried over from the old scene
+
+    def kernel_ms(self, name, reps=2):
+        """event-bracketed time of one kernel per sub-batch pass of pipe 0 (uwip_prof_*), alone on the chip"""
+        p = self.pipes[0]
+        p.ctx.prof_reset(); p.ctx.prof_enable(True)
+        for _ in range(reps):
+            p.run(self.parts[0])
+        p.sync()
+        r = p.ctx.prof_results()
+        p.ctx.prof_enable(False)
+        return r[name][0] / reps if name in r else None
 
     def on_all(self, fn):
         """fn(i) for every sub-batch, each on its own host thread (a uwip context is single-threaded; one per thread)"""
@@ -842,6 +905,19 @@ def main():
     if rank == 0:
         roof, kernels = roofline_report(args, pipe, rig.parts[0], dev, F, rig.Fs, H, W)
     barrier(world)
+    # the same timed region on further scenes (every rank; rank r's scenes differ from rank 0's as its headline scene does)
+    scenes = None
+    if args.scenes > 1:
+        sc_steps = max(1, min(args.steps, 5))
+        scenes = [{"seed0": rig.seed0, "frames_per_s": world * F * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "steps": args.steps,
+                   "sweep_ms_per_subbatch": (kernels.get("k_clahe_sweep") or {}).get("ms_per_subbatch"), "is": "the headline scene (`value`)"}]
+        for j in range(1, args.scenes):
+            rig.load_scene(1234 + 1000 * rank + 77777 * j)
+            dt_j = timed(rig, world, sc_steps, 1, host=False)
+            same_out = same_out and sharding.max_over_ranks(0.0 if outputs_identical(rig) else 1.0) == 0.0
+            scenes.append({"seed0": rig.seed0, "frames_per_s": world * F * sc_steps / dt_j, "ms_per_step": dt_j / sc_steps * 1e3,
+                           "steps": sc_steps, "sweep_ms_per_subbatch": rig.kernel_ms("k_clahe_sweep")})
+        barrier(world)
 
     rig.close()
     del rig, pipe
@@ -885,6 +961,11 @@ def main():
             "config": {"name": args.config,
                        "workload": f"full pipe bgdehaze->histretch->aclahe->videostrip-overlap on {W}x{H} uchar3 frames",
                        "frames_per_gpu_per_step": F, "streams_per_gpu": S, "stages": stages,
+                       "rules": {"overlap": "reference default: any homography from >= 4 good matches (videostrip.cpp:252-272)",
+                                 "detector_threshold": "reference-like default: fixed (SURF::create(400) is fixed, videostrip.cpp:206; the contrast-relative one is the opt-in)",
+                                 "dehaze_S": ("OPT-IN DEVIATION UWIP_DEHAZE_GUARD_S: S = 1 where BGDehaze.py:83 divides 0 by 0 (as written the frame turns black, "
+                                              "a trivial workload)") if GUARD_S else "reference default: unguarded (BGDehaze.py:83)",
+                                 "entry": "uwip_pipe_step / uwip_pipe_step_host (C ABI: the chain, carry and throttle are the library's)"},
                        "host_threads_submitting": 1 if os.environ.get("UWIP_BENCH_ONE_SUBMITTER", "1") == "1" else S,
                        "parallelism": f"frame-batch x{world}", "rank0_placement": placement},
             "check_note": "outputs_identical_across_streams: the sub-batch pipes of a rank hold the same frames, so after the timed "
@@ -895,6 +976,12 @@ def main():
             "value_note": "value: frames resident in HBM when the timed region starts (the contract's definition); "
                           "value_end_to_end: every frame uploaded from and downloaded to page-locked host memory inside the "
                           "timed region (the reference's own timed region, histretch.cpp:165-216), same steps, max over ranks",
+            "scenes": None if scenes is None else {
+                "per_scene": scenes,
+                "frames_per_s_min_median_max": [float(np.min([s["frames_per_s"] for s in scenes])), float(np.median([s["frames_per_s"] for s in scenes])),
+                                                float(np.max([s["frames_per_s"] for s in scenes]))],
+                "sweep_ms_min_max": [min(s["sweep_ms_per_subbatch"] or 0.0 for s in scenes), max(s["sweep_ms_per_subbatch"] or 0.0 for s in scenes)],
+                "note": "the timed region repeated on other synthetic scenes of the same size (seed0 differs); the headline `value` is scene 0"},
             "roofline": roof,
             "cpu_baseline": cpu,
             "host_buffers": host,

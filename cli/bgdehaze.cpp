@@ -1,10 +1,11 @@
 // bgdehaze -- Underwater Image Restoration by Blue-Green Channels Dehazing and Red Channel Correction.
 // The reference is `python main.py -i <index> -w <window>` over a file list from a missing util.py
 // (modules/bgdehaze/main.py:11,22-33); this takes the files directly:
-//   bgdehaze [-w N] [--rc] [--as-written] [--histretch LETTERS] <input> <output>
+//   bgdehaze [-w N] [--rc] [--guard-s] [--histretch LETTERS] <input> <output>
 //   -w N          window size of the dark channel (default 15, main.py:28-29)
 //   --rc          stop after RC_correction (BGDehaze.py:59-69) instead of adaptiveExp_map (:71-89)
-//   --as-written  keep the reference's 0/0 -> NaN -> black frame behaviour (SURVEY B-11)
+//   --guard-s     S = 1 where BGDehaze.py:83 divides 0 by 0 (a deviation; the default is the reference's behaviour: the
+//                 NaN spreads over the frame, which comes out black -- SURVEY B-11; --as-written is accepted and names it)
 //   --histretch L chain `histretch -c=L` (2/98 percent) on the result in the same run, e.g. --histretch RGB
 #include "cliutil.hpp"
 
@@ -12,7 +13,7 @@ int main(int argc, char **argv)
 {
     const Args a = parse_args(argc, argv, {"w", "window", "histretch"});
     if (a.pos.size() < 2 || a.has("help") || a.has("h")) {
-        std::printf("usage: bgdehaze [-w N] [--rc] [--as-written] [--histretch LETTERS] <input> <output>\n");
+        std::printf("usage: bgdehaze [-w N] [--rc] [--guard-s] [--histretch LETTERS] <input> <output>\n");
         return 0;
     }
     const int w = std::atoi(a.get("w", a.get("window", "15")).c_str());
@@ -23,7 +24,7 @@ int main(int argc, char **argv)
         uw::Context ctx(0);
         uw::DeviceMat in(ctx, as_mat(src));
         uw::DeviceMat out(ctx, src.rows, src.cols, 3);
-        const int flags = (a.has("rc") ? 0 : UWIP_DEHAZE_FULL) | (a.has("as-written") ? 0 : UWIP_DEHAZE_GUARD_S);
+        const int flags = (a.has("rc") ? 0 : UWIP_DEHAZE_FULL) | (a.has("guard-s") ? UWIP_DEHAZE_GUARD_S : 0);
         if (a.has("histretch"))
             ctx.check(uwip_dehaze_histretch(ctx.get(), in.batch(), out.batch(), w, flags, a.get("histretch", "RGB").c_str(), 2, 98, 0u));
         else

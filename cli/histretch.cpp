@@ -18,6 +18,7 @@ int main(int argc, char **argv)
                     "Argument 'c=<channels>' is a string containing an ordered list of desired channels to be stretched\n"
                     "\t-c=R|G|B\tfor RGB space\n\t-c=H|S|V\tfor HSV space\n\t-c=h|s|l\tfor hsl space\n\t-c=L|a|b\tfor Lab space\n"
                     "\t-c=Y|C|X\tfor YCrCb space\n\t--fixed-order\tkeep the stretch of the non-RGB letters (the reference discards it)\n"
+                    "\t--opencv32\tLab -> BGR as OpenCV 3.2 does (float form) instead of OpenCV 3.4.x (integer form, the default)\n"
                     "\tExample:\n\t$ histretch -c=RGB input.png output.png -cuda=1 -time=1\n");
         return 0;
     }
@@ -40,7 +41,7 @@ int main(int argc, char **argv)
             if (uw::numSpace(cChannel[nc]) == -1) std::printf("Option %c not recognized, skipping...\n", cChannel[nc]);
         }
         Stopwatch sw;
-        uw::histretch(ctx, as_mat(src), cChannel, 2, 98, a.has("fixed-order"));   // min_percent = 2, max_percent = 98 (histretch.cpp:154)
+        uw::histretch(ctx, as_mat(src), cChannel, 2, 98, a.has("fixed-order"), a.has("opencv32"));   // min_percent = 2, max_percent = 98 (histretch.cpp:154)
         if (Time == 1) std::printf("\nExecution Time GPU :%g ms \n", sw.ms());
     } catch (const uw::Error &e) {
         std::printf("error: %s\n", e.what());

@@ -35,9 +35,12 @@ int main(int argc, char **argv)
     const Args a = parse_args(argc, argv, {"k", "windowSize", "s", "timeSkip", "p", "minOverlap", "g", "gpus"});
     if (a.pos.size() < 2 || a.has("h") || a.has("help")) {
         std::printf("videostrip - smart extraction of video frames\n"
-                    "usage: videostrip [-k windowSize] [-s timeSkip] [-p minOverlap] [-r] [--png] [--min4] [-g gpus] <video.avi (Motion-JPEG) | frame_list.txt> <output_prefix>\n"
-                    "  --min4  accept any homography found from >= 4 good matches, as the reference does (videostrip.cpp:252-272);\n"
-                    "          default: a homography needs >= 6 RANSAC inliers\n");
+                    "usage: videostrip [-k windowSize] [-s timeSkip] [-p minOverlap] [-r] [--png] [--min6] [--relative-threshold] [-g gpus] <video.avi (Motion-JPEG) | frame_list.txt> <output_prefix>\n"
+                    "  default: any homography found from >= 4 good matches counts, as in the reference (videostrip.cpp:252-272)\n"
+                    "  --min6  a homography needs >= 6 RANSAC inliers, else -2.0 (a deviation; --min4 is accepted and names the default)\n"
+                    "  default: fixed detector threshold, as SURF's hessianThreshold is fixed (videostrip.cpp:206)\n"
+                    "  --relative-threshold  detector threshold relative to the frame's contrast: raw frames of turbid water have no\n"
+                    "          response above a fixed threshold (a deviation; use it together with --min6)\n");
         return 0;
     }
     const int kWindow = std::atoi(a.get("k", a.get("windowSize", std::to_string(DEFAULT_KWINDOW))).c_str());
@@ -45,7 +48,8 @@ int main(int argc, char **argv)
     const double minOverlap = std::atof(a.get("p", a.get("minOverlap", std::to_string(OVERLAP_MIN))).c_str());
     const std::string InputFile = a.pos[0], OutputFile = a.pos[1];
     const char *ext = a.has("png") ? "png" : "jpg";
-    const unsigned match_flags = a.has("min4") ? UWIP_OVERLAP_MIN4 : 0u;
+    const unsigned match_flags = a.has("min6") ? UWIP_OVERLAP_MIN6 : 0u;
+    const unsigned detect_flags = a.has("relative-threshold") ? UWIP_OVERLAP_RELATIVE_THRESHOLD : 0u;
     std::vector<std::string> frames;
     avi::Reader video;
     const bool is_avi = imgio::ends_with(InputFile, ".avi");
@@ -96,7 +100,7 @@ int main(int argc, char **argv)
                         for (size_t i = a0; i < a1; ++i) {
                             if (!read_at(first + i, im) || im.cols != vw || im.rows != vh) continue;
                             uw::DeviceMat d(ctx, as_mat(im));
-                            ctx.check(uwip_overlap_detect(ctx.get(), d.batch(), f, 0));
+                            ctx.check(uwip_overlap_detect_ex(ctx.get(), d.batch(), f, 0, detect_flags));
                             int32_t cnt = 0;
                             ctx.check(uwip_features_download(ctx.get(), f, 0, kps.data(), desc.data(), &cnt));
                             rec[i].kps.assign(kps.begin(), kps.begin() + cnt);
@@ -196,6 +200,7 @@ int main(int argc, char **argv)
         uw::Context ctx(0);
         uw::Videostrip vsx(ctx);
         vsx.match_flags = match_flags;
+        vsx.detect_flags = detect_flags;
         uw::keyframe kframe;
         imgio::Image kimg, frame, bestframe;
         uw::Mat res;                              // res_frame: cv::resize(frame, res_frame, Size(), f, f), main.cpp:311

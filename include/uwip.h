@@ -111,8 +111,10 @@ int uwip_memcpy_d2h_async(uwip_ctx *ctx, void *h_dst, const void *d_src, size_t 
  * SURVEY.md section 7 "PCIe feed").  One per device / rank: an upload lane and a
  * download lane, each a host thread with a stream of its own that serves the
  * first queued request whose dependency has completed (requests that depend on
- * the same context are served in their order; one whose stream is still busy
- * does not hold back the ready requests of other contexts).  A request with `after` != NULL starts once
+ * the same context are served in their order, and so are two requests of which
+ * one writes bytes -- host or device -- the other reads or writes; one whose
+ * stream is still busy does not hold back the ready requests of other
+ * contexts).  A request with `after` != NULL starts once
  * everything queued on that context's stream AT THE TIME OF THE CALL has
  * finished (the lane waits for it on the host, so a copy is only handed to the
  * DMA engine when it can run: no hardware queue ever holds a barrier packet
@@ -182,13 +184,19 @@ int uwip_imgChannelStretch(uwip_ctx *ctx, const uwip_batch_u8 *img, int channel,
  * uwip_histretch_ex with UWIP_HISTRETCH_FIXED_ORDER runs the evident intent
  * instead: convert (histretch.cpp:232), split / stretch / MERGE (:234-236,
  * :240), then convert back (:238) -- the stretch is kept.
- * The 8-bit conversions restate OpenCV 3.x's color.cpp (parity unpinned). */
+ * The 8-bit conversions restate OpenCV 3.x's color.cpp (parity unpinned).  Lab -> BGR exists in two forms there: OpenCV
+ * 3.4.x (the version INSTALL.md:47-63 pins) converts 8-bit Lab with the integer Lab2RGBinteger, OpenCV 3.2 (the version the
+ * module READMEs name) with the float Lab2RGB_f + inverse-gamma spline.  Default = 3.4.x, as for CLAHE's residual rule and
+ * the 3 x 3 blur's rounding; UWIP_HISTRETCH_OPENCV32 / opencv_rule = 1 selects the 3.2 form. */
 #define UWIP_HISTRETCH_FIXED_ORDER 1u
+#define UWIP_HISTRETCH_OPENCV32    2u
 int uwip_histretch_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi,
                       unsigned flags);
 /* cv::cvtColor(src, dst, COLOR_BGR2{HSV,HLS,Lab,YCrCb}) (to_bgr = 0) or COLOR_{..}2BGR (to_bgr = 1) on 8UC3 batches;
  * space = uwip_numSpace's index 1..4 (histretch.cpp:155-156).  dst may alias src. */
 int uwip_cvtColor(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int space, int to_bgr);
+/* opencv_rule: 0 = OpenCV 3.4.x, 1 = OpenCV 3.2 (only COLOR_Lab2BGR differs). */
+int uwip_cvtColor_ex(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int space, int to_bgr, int opencv_rule);
 int uwip_histretch(uwip_ctx *ctx, const uwip_batch_u8 *img, const char *letters, int lo, int hi);
 
 /* ---- aclahe (C1-C4) ----------------------------------------------------- */
@@ -380,12 +388,17 @@ int uwip_overlap_detect(uwip_ctx *ctx, const uwip_batch_u8 *frames, uwip_feature
  * holds under any in-plane rotation of the camera.  UWIP_OVERLAP_UPRIGHT skips the orientation estimate (SURF's
  * `upright` parameter): rotation tolerance then ends near 20 degrees. */
 #define UWIP_OVERLAP_UPRIGHT 1u
-/* By default the detector threshold is relative to the frame's own contrast: 1e-3 * min(1, (k / 0.5)^2), k = the frame's
- * contrast factor (70th percentile of the gradient magnitude).  The determinant-of-Hessian response scales with the
- * square of the contrast, and raw frames of turbid water -- what the reference's videostrip is run on -- have none above a
- * fixed threshold (the reference's own photograph PIS_T1A_259: no keypoint at all at 1e-3, 130 with the relative one).
- * UWIP_OVERLAP_FIXED_THRESHOLD keeps 1e-3 (SURF's hessianThreshold, videostrip.cpp:206, is fixed as well). */
+/* The detector threshold is FIXED by default (1e-3 on the scale-normalised determinant of the Hessian), as SURF's
+ * hessianThreshold is in the reference (SURF::create(400), videostrip.cpp:200,206).  UWIP_OVERLAP_RELATIVE_THRESHOLD (opt-in, a
+ * DEVIATION): the threshold follows the frame's own contrast, 1e-3 * min(1, (k / 0.5)^2), k = the frame's contrast factor
+ * (70th percentile of the gradient magnitude).  The response scales with the square of the contrast, and raw frames of
+ * turbid water -- what the reference's videostrip is run on -- have none above a fixed threshold (the reference's own
+ * photograph PIS_T1A_259: no keypoint at all at 1e-3, so calcOverlap answers -2.0 whatever the motion; 130 keypoints with
+ * the relative one).  It also finds a few dozen "keypoints" in pure sensor noise: combine it with UWIP_OVERLAP_MIN6.
+ * (Rounds 3-4 had the relative threshold as the default; UWIP_OVERLAP_FIXED_THRESHOLD is still accepted and names the
+ * default.) */
 #define UWIP_OVERLAP_FIXED_THRESHOLD 2u
+#define UWIP_OVERLAP_RELATIVE_THRESHOLD 16u
 int uwip_overlap_detect_ex(uwip_ctx *ctx, const uwip_batch_u8 *frames, uwip_features *feats, int first_slot, unsigned flags);
 /* parity taps: one slot's keypoints (uwip_keypoint[2048]) / packed 64-byte descriptors; and the
  * scale-space images of frame `frame` of the most recent uwip_overlap_detect call (host buffers
@@ -409,12 +422,15 @@ int uwip_overlap_match(uwip_ctx *ctx, const uwip_features *fq, const uwip_featur
                        const int32_t *h_pair_q, const int32_t *h_pair_t, int npairs, int videoWidth,
                        int videoHeight, uint32_t seed, float *d_ratio, int32_t *d_info, double *d_H,
                        int32_t *d_match_idx, int32_t *d_match_dist);
-/* Same with flags.  By default a homography supported by fewer than 6 RANSAC inliers is reported as none (-2.0): four
- * matches always fit one exactly, and with the contrast-relative detector threshold two frames of pure sensor noise now
- * and then produce four chance matches.  This is a DEVIATION from the reference, which takes whatever findHomography
- * returns for >= 4 good matches (videostrip.cpp:252-272).  UWIP_OVERLAP_MIN4 restores the reference's rule: any
- * hypothesis with >= 4 inliers (i.e. any solvable sample of four good matches) yields an overlap value. */
+/* Same with flags.  The default is the reference's rule (videostrip.cpp:252-256,270-272): -2.0 only when fewer than 4 good
+ * matches survive the ratio test or no homography is found; whatever findHomography returns for >= 4 good matches is
+ * used -- i.e. any hypothesis with >= 4 inliers (any solvable sample of four good matches) yields an overlap value.
+ * UWIP_OVERLAP_MIN6 (opt-in, a DEVIATION from the reference): a homography supported by fewer than 6 RANSAC inliers is
+ * reported as none (-2.0) -- four matches always fit one exactly, and with the contrast-relative detector threshold two
+ * frames of pure sensor noise now and then produce four chance matches.  (Rounds 3-4 had the two the other way round:
+ * UWIP_OVERLAP_MIN4 is still accepted and now names the default.) */
 #define UWIP_OVERLAP_MIN4 4u
+#define UWIP_OVERLAP_MIN6 8u
 int uwip_overlap_match_ex(uwip_ctx *ctx, const uwip_features *fq, const uwip_features *ft,
                           const int32_t *h_pair_q, const int32_t *h_pair_t, int npairs, int videoWidth,
                           int videoHeight, uint32_t seed, unsigned flags, float *d_ratio, int32_t *d_info,
@@ -425,6 +441,88 @@ int uwip_overlapArea(uwip_ctx *ctx, const double *d_H, int n, int videoWidth, in
 /* calcBlur(Mat frame), videostrip.cpp:170-184, on BGR frames (the reference passes the
  * resized frame, main.cpp:338,355): d_blur [frames]. */
 int uwip_calcBlur(uwip_ctx *ctx, const uwip_batch_u8 *frames, float *d_blur);
+
+/* ---- the whole per-frame chain ----------------------------------------------------------------------------- */
+/* bgdehaze -> histretch -> aclahe -> videostrip-overlap on batches of frames, as ONE object: what the reference runs as
+ * four tools back to back over files -- modules/bgdehaze/main.py:14-20, modules/histretch/src/histretch.cpp:217-254,
+ * modules/aclahe/src/aclahe.cpp:152-218 (+ python/ACLAHE.py:9-129, python/main.py:19-20), modules/videostrip/src/
+ * main.cpp:300-394 (calcOverlap of every frame against its predecessor, videostrip.cpp:192-289).  A pipe owns what the
+ * chain carries from step to step: the V planes, the feature slots (slot 0 = the previous batch's last frame, i.e. the
+ * `struct keyframe` cache of videostrip.hpp:62-68 carried across batches), the pair list, a throttle (at most
+ * `max_in_flight` steps queued on the stream: nothing in a step waits on the host, so an unthrottled caller would queue
+ * without bound), and -- for the host-buffer form -- two source and two result buffers in device memory with their copy
+ * tickets (GpuMat::upload ... download around the timed region, histretch.cpp:165-216, double-buffered).
+ * Stage definitions: dehaze = uwip_dehaze(w, dehaze_flags); histretch = uwip_histretch_ex(letters, lo, hi,
+ * histretch_flags) (the two chained through uwip_dehaze_histretch when both run); aclahe = uwip_bgr_to_v +
+ * uwip_aclahe_auto_ex(residual_rule, aclahe_flags) + uwip_hsv_replace_v; overlap = uwip_overlap_detect_ex(detect_flags)
+ * + uwip_overlap_match_ex(videoWidth, videoHeight, seed, match_flags) of frame i against frame i - 1 (frame 0 against the
+ * previous batch's last frame; in the very first batch against itself, main.cpp:284-297 takes the first frame as key frame).
+ * uwip_pipe_config_default fills in the REFERENCE's rules: letters "RGB", 2 / 98 percent, w = 15, UWIP_DEHAZE_FULL (S
+ * unguarded, BGDehaze.py:83), UWIP_ACLAHE_PREFILTER | UWIP_ACLAHE_ASYNC, OpenCV 3.4.x rounding, >= 4 good matches
+ * (videostrip.cpp:252-272), videoWidth x videoHeight = cols x rows (main.cpp:238-239), seed 1, two steps in flight.
+ * A pipe is bound to the context it was made from (its stream, its thread rule); destroy it before the context. */
+typedef struct uwip_pipe uwip_pipe;
+typedef struct uwip_pipe_config {
+    int32_t  frames, rows, cols;       /* batch geometry of every step: `frames` CV_8UC3 BGR frames of rows x cols */
+    char     letters[16];              /* histretch -c letters, NUL-terminated */
+    int32_t  lo, hi;                   /* histretch percentiles */
+    int32_t  w;                        /* bgdehaze window */
+    uint32_t dehaze_flags;             /* UWIP_DEHAZE_* */
+    uint32_t histretch_flags;          /* UWIP_HISTRETCH_* */
+    int32_t  residual_rule;            /* 0 = OpenCV 3.4.x, 1 = OpenCV 3.2 (CLAHE redistribution, 3x3 blur rounding) */
+    uint32_t aclahe_flags;             /* UWIP_ACLAHE_* */
+    uint32_t detect_flags;             /* UWIP_OVERLAP_UPRIGHT | UWIP_OVERLAP_RELATIVE_THRESHOLD */
+    uint32_t match_flags;              /* UWIP_OVERLAP_MIN6 */
+    int32_t  videoWidth, videoHeight;  /* the reference's globals; 0 = cols / rows */
+    uint32_t seed;                     /* RANSAC seed */
+    int32_t  max_in_flight;            /* steps queued before uwip_pipe_step waits for the oldest (>= 1) */
+    void    *d_staging;                /* host-buffer form: caller-owned device memory of uwip_pipe_staging_bytes() bytes,
+                                          or NULL = the pipe allocates it at the first uwip_pipe_step_host.  Layout:
+                                          src[2][frames][rows][cols][3] u8, work[2][...] u8, ratio[2][frames] f32 (256-byte
+                                          aligned), info[2][frames][8] i32 */
+} uwip_pipe_config;
+int uwip_pipe_config_default(uwip_pipe_config *cfg, int frames, int rows, int cols);
+size_t uwip_pipe_staging_bytes(const uwip_pipe_config *cfg);
+/* copier: the copy engine the host-buffer form uses (shared by all pipes of a rank), or NULL = the pipe makes its own at
+ * the first uwip_pipe_step_host. */
+int uwip_pipe_create(uwip_ctx *ctx, const uwip_pipe_config *cfg, uwip_copier *copier, uwip_pipe **out);
+int uwip_pipe_destroy(uwip_pipe *p);          /* drains the stream and the pipe's outstanding copies first */
+const char *uwip_pipe_last_error(const uwip_pipe *p);
+/* One step on frames resident in device memory: in -> out (distinct buffers of the configured geometry), d_ratio [frames]
+ * f32 = the overlap ratio of every frame against its predecessor (-2.0 / the value, videostrip.cpp:252-289), d_info (may
+ * be NULL) [frames][8] as uwip_overlap_match.  Asynchronous: returns when the step is queued (after waiting, if need be,
+ * until fewer than max_in_flight earlier steps are unfinished); uwip_pipe_sync drains. */
+int uwip_pipe_step(uwip_pipe *p, const uwip_batch_u8 *in, const uwip_batch_u8 *out, float *d_ratio, int32_t *d_info);
+/* The same, stage by stage (parity tests tap the chain between stages; a tool runs a part of it): `stages` is a mask of
+ * UWIP_PIPE_*.  Without UWIP_PIPE_DEHAZE `in` is ignored (may be NULL) and `out` is processed in place; d_ratio / d_info
+ * are used by UWIP_PIPE_OVERLAP only.  Not throttled. */
+#define UWIP_PIPE_DEHAZE    1u
+#define UWIP_PIPE_HISTRETCH 2u
+#define UWIP_PIPE_ACLAHE    4u
+#define UWIP_PIPE_OVERLAP   8u
+#define UWIP_PIPE_ALL       15u
+int uwip_pipe_stages(uwip_pipe *p, unsigned stages, const uwip_batch_u8 *in, const uwip_batch_u8 *out, float *d_ratio,
+                     int32_t *d_info);
+/* One step from / to page-locked host memory (uwip_host_alloc): h_in -> upload -> the four stages -> download -> h_out
+ * (frames) and, when h_ratio != NULL, h_ratio [frames] f32.  h_prefetch (may be NULL) is the NEXT step's h_in: its upload
+ * is requested now and runs under this step's kernels.  Returns without waiting for the device; tickets[0] = the upload of
+ * h_in (h_in may be refilled once it is complete), tickets[1] = the download of the frames (they leave as soon as the
+ * aclahe stage is done, under the overlap kernels), tickets[2] = the download of the ratios (0 when h_ratio is NULL):
+ * uwip_pipe_wait blocks the calling thread until that copy is complete.  The call itself waits (on the host, sleeping) for
+ * the upload of h_in and for the download of the step before last, whose device buffer it reuses. */
+int uwip_pipe_step_host(uwip_pipe *p, const void *h_in, void *h_out, float *h_ratio, const void *h_prefetch,
+                        uint64_t tickets[3]);
+int uwip_pipe_wait(uwip_pipe *p, uint64_t ticket);
+int uwip_pipe_sync(uwip_pipe *p);             /* the stream and every outstanding copy of this pipe */
+/* Forget the carried key frame: the next step's frame 0 is its own key frame again (a new video). */
+int uwip_pipe_reset(uwip_pipe *p);
+/* (BS, CL) the aclahe stage of the most recent step chose, h_bs / h_cl [frames] (waits for the stream). */
+int uwip_pipe_last_params(uwip_pipe *p, int32_t *h_bs, int32_t *h_cl);
+/* Device pointers of the most recent step's results, for callers that chain further device work: the V planes the
+ * aclahe stage left ([frames][rows][cols] u8, the unfiltered V of the stretched frames), and -- host-buffer form -- the
+ * frames / ratios / info of that step inside the staging area.  Any argument may be NULL. */
+int uwip_pipe_device_results(uwip_pipe *p, const uint8_t **d_v, const uint8_t **d_frames, const float **d_ratio,
+                             const int32_t **d_info);
 
 #ifdef __cplusplus
 }

@@ -147,10 +147,12 @@ inline void imgChannelStretch(Context &c, Mat imgOriginal, Mat imgStretched, int
 }
 
 // the per-letter loop of histretch.cpp:217-254 on a BGR image, in place
-inline void histretch(Context &c, Mat src, const std::string &cChannel, int min_percent = 2, int max_percent = 98, bool fixed_order = false)
+inline void histretch(Context &c, Mat src, const std::string &cChannel, int min_percent = 2, int max_percent = 98, bool fixed_order = false,
+                      bool opencv32 = false)
 {
     DeviceMat d(c, src);
-    c.check(uwip_histretch_ex(c.get(), d.batch(), cChannel.c_str(), min_percent, max_percent, fixed_order ? UWIP_HISTRETCH_FIXED_ORDER : 0u));
+    c.check(uwip_histretch_ex(c.get(), d.batch(), cChannel.c_str(), min_percent, max_percent,
+                              (fixed_order ? UWIP_HISTRETCH_FIXED_ORDER : 0u) | (opencv32 ? UWIP_HISTRETCH_OPENCV32 : 0u)));
     d.download(src);
 }
 
@@ -164,7 +166,8 @@ struct keyframe {                 // videostrip.hpp:62-68 (keypoints/descriptors
 class Videostrip {
 public:
     int videoWidth = 0, videoHeight = 0;          // the reference's globals (main.cpp:45-46)
-    unsigned match_flags = 0;                     // UWIP_OVERLAP_MIN4: the reference's ">= 4 good matches" rule (videostrip.cpp:252-272)
+    unsigned match_flags = 0;                     // 0 = the reference's ">= 4 good matches" rule (videostrip.cpp:252-272); UWIP_OVERLAP_MIN6 = >= 6 inliers
+    unsigned detect_flags = 0;                    // 0 = fixed detector threshold (SURF::create(400) is fixed, videostrip.cpp:206); UWIP_OVERLAP_RELATIVE_THRESHOLD
     explicit Videostrip(Context &c) : c_(c)
     {
         c_.check(uwip_features_create(c_.get(), 1, &obj_));
@@ -181,11 +184,11 @@ public:
         initKeyframe(*kframe);
         if (kframe->new_img) {
             DeviceMat k(c_, kframe->img);
-            c_.check(uwip_overlap_detect(c_.get(), k.batch(), kframe->feats, 0));
+            c_.check(uwip_overlap_detect_ex(c_.get(), k.batch(), kframe->feats, 0, detect_flags));
             kframe->new_img = false;
         }
         DeviceMat o(c_, img_object);
-        c_.check(uwip_overlap_detect(c_.get(), o.batch(), obj_, 0));
+        c_.check(uwip_overlap_detect_ex(c_.get(), o.batch(), obj_, 0, detect_flags));
         int32_t q = 0, t = 0;
         c_.check(uwip_overlap_match_ex(c_.get(), obj_, kframe->feats, &q, &t, 1, videoWidth, videoHeight, seed, match_flags,
                                        (float *)scratch_, nullptr, nullptr, nullptr, nullptr));

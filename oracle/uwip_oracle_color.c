@@ -194,11 +194,77 @@ static void lab2bgr(const uint8_t *p, uint8_t *o)
     }
 }
 
-/* cvtColor on an 8UC3 image: space 1 HSV, 2 HLS, 3 Lab, 4 YCrCb; dir 0 from BGR, 1 to BGR.  out may alias img. */
+/* ---- Lab -> BGR, OpenCV 3.4.x: Lab2RGBinteger (imgproc/src/color_lab.cpp of 3.4.x, restated from memory -- PARITY UNPINNED:
+ * the reference holds no fixture and OpenCV is not importable here).  INSTALL.md:47-63 pins 3.4.6, whose cvtColor takes this
+ * integer path for 8-bit Lab2BGR; the float form above is what OpenCV 3.2 (the READMEs' version) does.
+ *   y, ify      = LabToYF_b[L]                      (base 2^14: y = Y/Yn, ify = f(Y/Yn))
+ *   adiv, bdiv  = (a - 128) / 500, (b - 128) / 200  in base 2^14 by multiply-shift
+ *   x, z        = abToXZ_b[ify + adiv], abToXZ_b[ify - bdiv]   (cube, or the linear branch below 6/29)
+ *   r, g, b     = descale(C . (x, y, z), 14) clamped to [0, 4095] -> sRGBInvGammaTab_b
+ * Tables as initLabTabs builds them with softfloat (= correctly rounded float32 operations; cvRound = lrintf). */
+static uint16_t g_yf[512], g_invgamma_b[4096];
+static int g_Ki[9];
+static int g_labi_ready = 0;
+static void labi_init(void)
+{
+    static const double X2R[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311};
+    static const double W[3] = {0.950456, 1., 1.088754};
+    const int BASE = 1 << 14;
+    if (g_labi_ready) return;
+    for (int i = 0; i < 256; ++i) {
+        long y, ify;
+        if (i <= 20) {
+            y = lrintf((float)(i * BASE * 20 * 9) / (float)(17 * 29 * 29 * 29));
+            ify = lrintf((float)BASE * ((float)16 / (float)116 + (float)(i * 5) / (float)(3 * 17 * 29)));
+        } else {
+            const float fy = (float)(i * 100 * BASE) / (float)(255 * 116) + (float)(16 * BASE) / (float)116;
+            ify = lrintf(fy);
+            y = lrintf(fy * fy * fy / (float)(BASE * BASE));
+        }
+        g_yf[i * 2] = (uint16_t)y; g_yf[i * 2 + 1] = (uint16_t)ify;
+    }
+    {
+        const float thr = (float)7827 / (float)2500000, lowScale = (float)323 / (float)25, power = (float)12 / (float)5, xshift = (float)11 / (float)200;
+        for (int i = 0; i < 4096; ++i) {
+            const float x = (1.0f / 4096.0f) * (float)i;
+            const float g = x <= thr ? x * lowScale : powf(x, 1.0f / power) * (1.0f + xshift) - xshift;
+            g_invgamma_b[i] = (uint16_t)lrintf(255.0f * g);
+        }
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) g_Ki[j * 3 + i] = (int)lrint(4096.0 * X2R[j * 3 + i] * W[i]);
+    g_labi_ready = 1;
+}
+static int ab_to_xz(int i)
+{
+    const int BASE = 1 << 14;
+    return i <= 3390 ? i * 108 / 841 - BASE * 16 / 116 * 108 / 841 : i * i / BASE * i / BASE;
+}
+static void lab2bgr_int(const uint8_t *p, uint8_t *o)
+{
+    const int BASE = 1 << 14;
+    const int y = g_yf[p[0] * 2], ify = g_yf[p[0] * 2 + 1];
+    const int adiv = ((5 * p[1] * 53687 + (1 << 7)) >> 13) - 128 * BASE / 500;
+    const int bdiv = ((p[2] * 41943 + (1 << 4)) >> 9) - 128 * BASE / 200 + 1;
+    const int x = ab_to_xz(ify + adiv), z = ab_to_xz(ify - bdiv);
+    int ro = descale(g_Ki[0] * x + g_Ki[1] * y + g_Ki[2] * z, 14);
+    int go = descale(g_Ki[3] * x + g_Ki[4] * y + g_Ki[5] * z, 14);
+    int bo = descale(g_Ki[6] * x + g_Ki[7] * y + g_Ki[8] * z, 14);
+    ro = ro < 0 ? 0 : (ro > 4095 ? 4095 : ro); go = go < 0 ? 0 : (go > 4095 ? 4095 : go); bo = bo < 0 ? 0 : (bo > 4095 ? 4095 : bo);
+    o[0] = (uint8_t)sat8i(g_invgamma_b[bo]); o[1] = (uint8_t)sat8i(g_invgamma_b[go]); o[2] = (uint8_t)sat8i(g_invgamma_b[ro]);
+}
+
+/* cvtColor on an 8UC3 image: space 1 HSV, 2 HLS, 3 Lab, 4 YCrCb; dir 0 from BGR, 1 to BGR.  out may alias img.
+ * rule: 0 = OpenCV 3.4.x (Lab -> BGR by the integer form), 1 = OpenCV 3.2 (the float form); only Lab's inverse differs. */
+ORC_API int orc_cvt_space_ex(const uint8_t *img, int rows, int cols, size_t step, uint8_t *out, size_t ostep, int space, int dir, int rule);
 ORC_API int orc_cvt_space(const uint8_t *img, int rows, int cols, size_t step, uint8_t *out, size_t ostep, int space, int dir)
 {
-    if (space < 1 || space > 4 || dir < 0 || dir > 1) return -1;
-    if (space == 3) lab_init();
+    return orc_cvt_space_ex(img, rows, cols, step, out, ostep, space, dir, 0);
+}
+ORC_API int orc_cvt_space_ex(const uint8_t *img, int rows, int cols, size_t step, uint8_t *out, size_t ostep, int space, int dir, int rule)
+{
+    if (space < 1 || space > 4 || dir < 0 || dir > 1 || rule < 0 || rule > 1) return -1;
+    if (space == 3) { lab_init(); labi_init(); }
     for (int y = 0; y < rows; ++y)
         for (int x = 0; x < cols; ++x) {
             const uint8_t *p = img + (size_t)y * step + (size_t)x * 3;
@@ -207,7 +273,7 @@ ORC_API int orc_cvt_space(const uint8_t *img, int rows, int cols, size_t step, u
                 if (dir == 0) { int h, s, v; orc_bgr_to_hsv_px(p[0], p[1], p[2], &h, &s, &v); o[0] = (uint8_t)h; o[1] = (uint8_t)s; o[2] = (uint8_t)v; }
                 else orc_hsv_to_bgr_px(p[0], p[1], p[2], o);
             } else if (space == 2) { if (dir == 0) bgr2hls(p, o); else hls2bgr(p, o); }
-            else if (space == 3) { if (dir == 0) bgr2lab(p, o); else lab2bgr(p, o); }
+            else if (space == 3) { if (dir == 0) bgr2lab(p, o); else if (rule == 0) lab2bgr_int(p, o); else lab2bgr(p, o); }
             else { if (dir == 0) bgr2ycc(p, o); else ycc2bgr(p, o); }
             uint8_t *q = out + (size_t)y * ostep + (size_t)x * 3;
             q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
@@ -215,19 +281,21 @@ ORC_API int orc_cvt_space(const uint8_t *img, int rows, int cols, size_t step, u
     return 0;
 }
 
-/* the per-letter loop of histretch.cpp:217-254 with every colour space; fixed_order = 0: as written (B-3, the non-BGR
- * letters leave the 8-bit colour round trip), 1: convert, stretch the letter's plane, merge, convert back */
-ORC_API int orc_histretch_bgr_ex(uint8_t *img, int rows, int cols, size_t step, const char *letters, int lo, int hi, int fixed_order)
+/* the per-letter loop of histretch.cpp:217-254 with every colour space; flags bit 0 (fixed order) = 0: as written (B-3, the
+ * non-BGR letters leave the 8-bit colour round trip), 1: convert, stretch the letter's plane, merge, convert back; bit 1 =
+ * OpenCV 3.2's float Lab inverse instead of 3.4.x's integer one (uwip.h UWIP_HISTRETCH_OPENCV32) */
+ORC_API int orc_histretch_bgr_ex(uint8_t *img, int rows, int cols, size_t step, const char *letters, int lo, int hi, int flags)
 {
+    const int fixed_order = flags & 1, rule = (flags >> 1) & 1;
     uint8_t *tmp = (uint8_t *)malloc((size_t)rows * cols * 3 + 1);
     if (!tmp) return -1;
     for (const char *c = letters; *c; ++c) {
         const int ch = orc_numChannel(*c), sp = orc_numSpace(*c);
         if (sp == -1) continue;
         if (sp == 0) { orc_imgChannelStretch(img + ch, rows, cols, step, 3, lo, hi); continue; }
-        orc_cvt_space(img, rows, cols, step, tmp, (size_t)cols * 3, sp, 0);
+        orc_cvt_space_ex(img, rows, cols, step, tmp, (size_t)cols * 3, sp, 0, rule);
         if (fixed_order) orc_imgChannelStretch(tmp + ch, rows, cols, (size_t)cols * 3, 3, lo, hi);
-        orc_cvt_space(tmp, rows, cols, (size_t)cols * 3, img, step, sp, 1);
+        orc_cvt_space_ex(tmp, rows, cols, (size_t)cols * 3, img, step, sp, 1, rule);
     }
     free(tmp);
     return 0;

@@ -41,7 +41,7 @@
  * matches (videostrip.cpp:252-272) -- but four matches always fit SOME homography exactly, and with the contrast-relative
  * detector threshold pure sensor noise yields a few dozen keypoints of which 4 can pass the ratio test by chance: such a
  * fit is reported as -2.0 ("no homography"), the sentinel main.cpp:321-326 turns into "do not trigger". */
-#define OV_MIN_INLIERS 6
+#define OV_MIN_INLIERS 4          /* the reference's rule (videostrip.cpp:252-272); 6 = the opt-in strict rule */
 
 typedef struct {
     float x, y;          /* refined position (pixels of the 640-wide image) */
@@ -324,14 +324,15 @@ static void build_scale_space(const uint8_t *gray, int h, int w, scale_space *S)
  * is therefore taken relative to the frame's own contrast factor k (the 70th percentile of the gradient magnitude, already
  * computed for the diffusion): OV_DTHRESH * min(1, (k / OV_KC_REF)^2).  A frame as contrasted as the reference's
  * BUL_T1A_0028 (k = 0.51) keeps 1e-3; PIS_T1A_259 (k = 0.041) gets 6.7e-6 and 130 keypoints, and its overlap under yaw and
- * zoom is found within 0.004 (tests).  flags bit 1 keeps the fixed threshold (SURF's hessianThreshold is fixed too). */
+ * zoom is found within 0.004 (tests).  The default is the fixed threshold (SURF's hessianThreshold is fixed too); flags bit 4
+ * (16, uwip.h UWIP_OVERLAP_RELATIVE_THRESHOLD) selects the relative one, bit 1 is accepted and names the default. */
 static int detect(const scale_space *S, orc_keypoint *kps /* OV_MAXKP */, int flags)
 {
     const int h = S->h, w = S->w;
     const float kr = S->kcontrast / OV_KC_REF;
     float ks = kr * kr;
     if (!(ks < 1.0f)) ks = 1.0f;
-    const float dthr = (flags & 2) ? OV_DTHRESH : OV_DTHRESH * ks;
+    const float dthr = (flags & 16) ? OV_DTHRESH * ks : OV_DTHRESH;
     size_t cap = 65536, cnt = 0;
     orc_keypoint *all = (orc_keypoint *)malloc(cap * sizeof(orc_keypoint));
     for (int lv = 0; lv < OV_NLEVELS; ++lv) {
@@ -559,7 +560,7 @@ static void describe(const scale_space *S, const orc_keypoint *kps, int n, uint8
     }
 }
 
-/* flags: bit 0 = upright (no orientation estimate: SURF's `upright` parameter); bit 1 = fixed detector threshold */
+/* flags: bit 0 = upright (no orientation estimate: SURF's `upright` parameter); bit 4 (16) = contrast-relative detector threshold */
 ORC_API int orc_detect_describe_ex(const uint8_t *gray, int h, int w, orc_keypoint *kps, uint8_t *desc, float *kcontrast, int flags)
 {
     scale_space S;
@@ -762,8 +763,8 @@ ORC_API int orc_find_homography(const float *ox, const float *oy, const float *s
     return orc_find_homography_ex(ox, oy, sx, sy, n, w, h, seed, H, OV_MIN_INLIERS);
 }
 
-/* min_inliers: OV_MIN_INLIERS (6) by default; 4 = the reference's rule (any homography findHomography returns for >= 4
- * good matches is used, videostrip.cpp:252-272) */
+/* min_inliers: OV_MIN_INLIERS (4) by default = the reference's rule (any homography findHomography returns for >= 4
+ * good matches is used, videostrip.cpp:252-272); 6 = the strict opt-in rule (uwip.h UWIP_OVERLAP_MIN6) */
 ORC_API int orc_find_homography_ex(const float *ox, const float *oy, const float *sx, const float *sy, int n, int w, int h,
                                    uint32_t seed, double H[9], int min_inliers)
 {
@@ -977,7 +978,7 @@ ORC_API float orc_calcOverlap(const uint8_t *key, const uint8_t *obj, int rows, 
     return orc_calcOverlap_ex(key, obj, rows, cols, step, videoWidth, videoHeight, seed, info, Hout, 0);
 }
 
-/* flags: bit 0 = upright descriptors, bit 1 = fixed detector threshold, bit 2 = the reference's ">= 4 matches" rule */
+/* flags: bit 0 = upright descriptors, bit 4 (16) = contrast-relative detector threshold, bit 2 = accepted, names the default (the reference's ">= 4 matches" rule), bit 3 = >= 6 inliers (UWIP_OVERLAP_MIN6) */
 ORC_API float orc_calcOverlap_ex(const uint8_t *key, const uint8_t *obj, int rows, int cols, size_t step, int videoWidth,
                                  int videoHeight, uint32_t seed, int32_t *info, double *Hout, int flags)
 {
@@ -1001,7 +1002,7 @@ ORC_API float orc_calcOverlap_ex(const uint8_t *key, const uint8_t *obj, int row
         float *ox = (float *)malloc(4 * ng), *oy = (float *)malloc(4 * ng), *sx = (float *)malloc(4 * ng), *sy = (float *)malloc(4 * ng);
         for (int i = 0; i < ng; ++i) { ox[i] = ko[gq[i]].x; oy[i] = ko[gq[i]].y; sx[i] = kk[gt[i]].x; sy[i] = kk[gt[i]].y; }
         double H[9];
-        ninl = orc_find_homography_ex(ox, oy, sx, sy, ng, ow, oh, seed, H, (flags & 4) ? 4 : OV_MIN_INLIERS);
+        ninl = orc_find_homography_ex(ox, oy, sx, sy, ng, ow, oh, seed, H, (flags & 8) ? 6 : OV_MIN_INLIERS);
         if (ninl > 0) {
             result = orc_overlapArea(H, videoWidth, videoHeight, &ovc);
             if (Hout) memcpy(Hout, H, sizeof H);

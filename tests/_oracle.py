@@ -147,12 +147,12 @@ class Oracle:
         self.lib.orc_resize_gray(img, img.shape[0], img.shape[1], img.strides[0], oh, ow, g, small.ctypes.data)
         return small
 
-    def detect_describe(self, gray, upright=False, fixed_threshold=False):
+    def detect_describe(self, gray, upright=False, relative_threshold=False):
         gray = np.ascontiguousarray(gray)
         kps = np.zeros(2048, self.KP)
         desc = np.zeros((2048, 64), np.uint8)
         kc = C.c_float(0)
-        n = self.lib.orc_detect_describe_ex(gray, gray.shape[0], gray.shape[1], kps.ctypes.data, desc, C.byref(kc), (1 if upright else 0) | (2 if fixed_threshold else 0))
+        n = self.lib.orc_detect_describe_ex(gray, gray.shape[0], gray.shape[1], kps.ctypes.data, desc, C.byref(kc), (1 if upright else 0) | (16 if relative_threshold else 0))
         return kps[:n].copy(), desc[:n].copy(), kc.value
 
     def scale_space_level(self, gray, level):
@@ -174,7 +174,7 @@ class Oracle:
         n = self.lib.orc_ratio_test(np.ascontiguousarray(idx).reshape(-1), np.ascontiguousarray(dist).reshape(-1), nq, nt, gq, gt)
         return gq[:n], gt[:n]
 
-    def find_homography(self, ox, oy, sx, sy, w, h, seed=1, min_inliers=6):
+    def find_homography(self, ox, oy, sx, sy, w, h, seed=1, min_inliers=4):
         H = (C.c_double * 9)()
         a = [np.ascontiguousarray(v, np.float32) for v in (ox, oy, sx, sy)]
         n = self.lib.orc_find_homography_ex(a[0], a[1], a[2], a[3], len(a[0]), w, h, seed, H, min_inliers)
@@ -186,14 +186,14 @@ class Oracle:
         r = self.lib.orc_overlapArea(Hc, vw, vh, C.byref(cnt))
         return float(r), cnt.value
 
-    def calcOverlap(self, key, obj, vw=None, vh=None, seed=1, upright=False, fixed_threshold=False, min4=False):
+    def calcOverlap(self, key, obj, vw=None, vh=None, seed=1, upright=False, relative_threshold=False, min6=False):
         key, obj = np.ascontiguousarray(key), np.ascontiguousarray(obj)
         vw = key.shape[1] if vw is None else vw
         vh = key.shape[0] if vh is None else vh
         info = (C.c_int32 * 8)()
         H = (C.c_double * 9)()
         r = self.lib.orc_calcOverlap_ex(key, obj, key.shape[0], key.shape[1], key.strides[0], vw, vh, seed, info, H,
-                                        (1 if upright else 0) | (2 if fixed_threshold else 0) | (4 if min4 else 0))
+                                        (1 if upright else 0) | (16 if relative_threshold else 0) | (8 if min6 else 0))
         return float(r), list(info)[:5], np.array(list(H)).reshape(3, 3)
 
     # ---- numpy-friendly wrappers ----
@@ -219,22 +219,24 @@ class Oracle:
         rc = self.lib.orc_histretch_bgr(out, out.shape[0], out.shape[1], out.strides[0], letters.encode(), lo, hi)
         return out, rc
 
-    def cvt_space(self, img, space, to_bgr=False):
-        """cv::cvtColor BGR2{HSV,HLS,Lab,YCrCb} (space 1..4) or back, 8UC3 (oracle/uwip_oracle_color.c)"""
+    def cvt_space(self, img, space, to_bgr=False, opencv32=False):
+        """cv::cvtColor BGR2{HSV,HLS,Lab,YCrCb} (space 1..4) or back, 8UC3 (oracle/uwip_oracle_color.c); opencv32: Lab -> BGR
+        in OpenCV 3.2's float form instead of 3.4.x's integer one"""
         img = np.ascontiguousarray(img)
         out = np.zeros_like(img)
-        f = self.lib.orc_cvt_space
+        f = self.lib.orc_cvt_space_ex
         f.restype = C.c_int
-        f.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_int]
-        assert f(img.reshape(-1), img.shape[0], img.shape[1], img.strides[0], out.reshape(-1), out.strides[0], space, 1 if to_bgr else 0) == 0
+        f.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, u8p, C.c_size_t, C.c_int, C.c_int, C.c_int]
+        assert f(img.reshape(-1), img.shape[0], img.shape[1], img.strides[0], out.reshape(-1), out.strides[0], space, 1 if to_bgr else 0,
+                 1 if opencv32 else 0) == 0
         return out
 
-    def histretch_ex(self, img, letters, lo=2, hi=98, fixed_order=False):
+    def histretch_ex(self, img, letters, lo=2, hi=98, fixed_order=False, opencv32=False):
         out = np.ascontiguousarray(img).copy()
         f = self.lib.orc_histretch_bgr_ex
         f.restype = C.c_int
         f.argtypes = [u8p, C.c_int, C.c_int, C.c_size_t, C.c_char_p, C.c_int, C.c_int, C.c_int]
-        assert f(out.reshape(-1), out.shape[0], out.shape[1], out.strides[0], letters.encode(), lo, hi, 1 if fixed_order else 0) == 0
+        assert f(out.reshape(-1), out.shape[0], out.shape[1], out.strides[0], letters.encode(), lo, hi, (1 if fixed_order else 0) | (2 if opencv32 else 0)) == 0
         return out
 
     def imgChannelStretch(self, plane, lo, hi):

@@ -3,6 +3,9 @@ import sys
 
 import pytest
 
+# the library's test hooks (UWIP_ACLAHE_TEST_FORCE_CL ...) are dead unless the process starts with this (csrc/uwip_internal.hpp)
+os.environ["UWIP_TEST_HOOKS"] = "1"
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -46,7 +46,7 @@ def test_bench_arrangement_8_streams_1080p_vs_oracle(orc):
         assert params[i] == params[0], i
         assert np.array_equal(infos[i], infos[0]), i
     # the device's own dehaze output for these frames (a separate pipe, the un-chained call)
-    probe = FramePipe(0, Fs, H, W)
+    probe = FramePipe(0, Fs, H, W, guard_s=bench.GUARD_S)
     probe.stage_dehaze(rig.parts[0])
     torch.cuda.synchronize()
     dehazed = probe.work.cpu().numpy().copy()

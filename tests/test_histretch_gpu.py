@@ -134,6 +134,13 @@ def test_cvtColor_both_directions_vs_oracle(ctx, orc, space):
         assert np.array_equal(fwd, orc.cvt_space(img, space)), space
         back = pp.cvtColor(ctx, _dev(fwd), space, to_bgr=True).cpu().numpy()
         assert np.array_equal(back, orc.cvt_space(fwd, space, True)), space
+        if space == 3:
+            # Lab -> BGR in both OpenCV forms: 3.4.x integer (the default, above) and 3.2 float; ALL 2^24 Lab triples would
+            # take a while -- a dense random sample of them (most are out of gamut: the clamps are exercised too)
+            lab = rng.integers(0, 256, (512, 512, 3), dtype=np.uint8)
+            for v32 in (False, True):
+                got = pp.cvtColor(ctx, _dev(lab), 3, to_bgr=True, opencv32=v32).cpu().numpy()
+                assert np.array_equal(got, orc.cvt_space(lab, 3, True, opencv32=v32)), v32
     batch = rng.integers(0, 256, (3, 40, 56, 3), dtype=np.uint8)
     got = pp.cvtColor(ctx, _dev(batch), space).cpu().numpy()
     for f in range(3):
@@ -149,6 +156,10 @@ def test_hls_lab_letters_and_fixed_order(ctx, orc, letters, fixed):
     t = _dev(img)
     pp.histretch(ctx, t, letters, fixed_order=fixed)
     assert np.array_equal(t.cpu().numpy(), orc.histretch_ex(img, letters, fixed_order=fixed)), (letters, fixed)
+    if any(c in "Lab" for c in letters):
+        t = _dev(img)
+        pp.histretch(ctx, t, letters, fixed_order=fixed, opencv32=True)             # UWIP_HISTRETCH_OPENCV32
+        assert np.array_equal(t.cpu().numpy(), orc.histretch_ex(img, letters, fixed_order=fixed, opencv32=True)), (letters, fixed)
 
 
 @pytest.mark.parametrize("letters", ["V", "HY", "RSC"])

@@ -423,15 +423,15 @@ def test_colour_space_known_answers(orc):
 
 
 def test_min_inliers_rule_and_the_references_four_match_rule(orc):
-    """Deviation with a switch (uwip.h UWIP_OVERLAP_MIN4): by default a homography needs >= 6 RANSAC inliers; the reference
-    takes whatever findHomography returns for >= 4 good matches (videostrip.cpp:252-272).  Four consistent matches + one
-    outlier: none by default, a homography with 4 inliers under the reference's rule."""
+    """The default is the reference's rule: whatever findHomography returns for >= 4 good matches (videostrip.cpp:252-272);
+    the switch (uwip.h UWIP_OVERLAP_MIN6) asks for >= 6 RANSAC inliers.  Four consistent matches + one outlier: a homography
+    with 4 inliers by default, none under the strict rule."""
     rng = np.random.default_rng(1)
     ox = rng.uniform(50, 600, 5).astype(np.float32); oy = rng.uniform(50, 300, 5).astype(np.float32)
     sx, sy = ox + 10, oy - 5
     sx[4] += 80
-    assert orc.find_homography(ox, oy, sx, sy, 640, 360, seed=1)[0] == 0
-    n, H = orc.find_homography(ox, oy, sx, sy, 640, 360, seed=1, min_inliers=4)
+    assert orc.find_homography(ox, oy, sx, sy, 640, 360, seed=1, min_inliers=6)[0] == 0
+    n, H = orc.find_homography(ox, oy, sx, sy, 640, 360, seed=1)
     assert n == 4 and np.abs(H - np.array([[1, 0, 10], [0, 1, -5], [0, 0, 1]])).max() < 1e-6
     assert orc.find_homography(ox[:3], oy[:3], sx[:3], sy[:3], 640, 360, seed=1, min_inliers=4)[0] == 0      # < 4 matches: -2.0 either way
 
@@ -481,27 +481,76 @@ def _real_photo_pair(name, theta, scale, rows=720, cols=1280):
     return img[oy:oy + rows, ox:ox + cols].copy(), cur, A
 
 
+def test_lab_to_bgr_both_opencv_versions(orc):
+    """COLOR_Lab2BGR, 8-bit, in its two OpenCV 3.x forms: 3.4.x's integer Lab2RGBinteger (the default: the
+    version INSTALL.md pins) and 3.2's float form.  Known answers: the Lab triples OpenCV gives for the primaries, white,
+    black and mid grey go back to those colours under BOTH forms; every grey round-trips within the 8-bit L quantisation;
+    an independent float64 evaluation of the CIE formulas agrees with the integer form within 2 levels on in-gamut
+    colours; and the two forms agree with each other within 2 levels on 99.9 % of a dense sample (they are two roundings
+    of one function).  parity unpinned beyond that (restated from memory; no OpenCV here)."""
+    lab = np.array([[[136, 208, 195], [224, 42, 211], [82, 207, 20], [255, 128, 128], [0, 128, 128], [137, 128, 128]]], np.uint8)
+    # (8-bit a / b are rounded, and the inverse gamma is steep near zero: the exact float64 inverse of these 8-bit triples is
+    # not the pure primary but e.g. (4, 255, 7) for green -- both forms must land within one level of THAT)
+    want = [[1, 2, 255], [4, 255, 7], [255, 1, 0], [255, 255, 255], [0, 0, 0], [128, 128, 128]]
+    for v32 in (False, True):
+        got = orc.cvt_space(lab, 3, True, opencv32=v32)[0].astype(int)
+        assert np.abs(got - np.array(want)).max() <= 1, (v32, got.tolist())
+    assert orc.cvt_space(lab, 3, True)[0][3:].tolist() == [[255, 255, 255], [0, 0, 0], [128, 128, 128]]
+    grey = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)
+    for v32 in (False, True):
+        back = orc.cvt_space(orc.cvt_space(grey, 3), 3, True, opencv32=v32).astype(int)
+        # (the integer form's rounded 2^12 coefficient rows do not sum to exactly 4096: 15 of the 256 greys come back with one
+        # channel a level apart; the float form keeps them neutral)
+        assert np.abs(back - grey.astype(int)).max() <= 1 and (back.max(-1) - back.min(-1)).max() <= (0 if v32 else 1)
+    # independent float64 CIE L*a*b* -> sRGB of in-gamut colours (forward by the oracle, which the primaries above pin)
+    rng = np.random.default_rng(9)
+    bgr = rng.integers(0, 256, (64, 64, 3), dtype=np.uint8)
+    L8 = orc.cvt_space(bgr, 3)
+    L = L8[..., 0] * (100.0 / 255.0); a = L8[..., 1] - 128.0; b = L8[..., 2] - 128.0
+    fy = (L + 16.0) / 116.0
+    fx, fz = fy + a / 500.0, fy - b / 200.0
+    finv = lambda t: np.where(t > 6.0 / 29.0, t ** 3, (t - 16.0 / 116.0) / 7.787)
+    X, Y, Z = finv(fx) * 0.950456, np.where(L > 8.0, fy ** 3, L / 903.3), finv(fz) * 1.088754
+    M = np.array([[3.240479, -1.53715, -0.498535], [-0.969256, 1.875991, 0.041556], [0.055648, -0.204043, 1.057311]])
+    rgb = np.clip(np.stack([X, Y, Z], -1) @ M.T, 0, 1)
+    srgb = np.where(rgb <= 0.0031308, 12.92 * rgb, 1.055 * np.power(rgb, 1 / 2.4) - 0.055)
+    ref = np.rint(255 * srgb)[..., ::-1]
+    for v32 in (False, True):
+        d = np.abs(orc.cvt_space(L8, 3, True, opencv32=v32).astype(int) - ref)
+        assert d.max() <= 2, (v32, d.max())
+    dense = rng.integers(0, 256, (256, 256, 3), dtype=np.uint8)
+    dense[..., 1:] = 128 + (dense[..., 1:].astype(int) - 128) // 2             # keep most of the sample inside the gamut
+    dd = np.abs(orc.cvt_space(dense, 3, True).astype(int) - orc.cvt_space(dense, 3, True, opencv32=True).astype(int))
+    assert np.percentile(dd, 99.9) <= 2 and (dd != 0).any()                   # two forms, not one
+    # histretch letters take the version switch along
+    img = rng.integers(40, 200, (48, 64, 3), dtype=np.uint8)
+    assert np.array_equal(orc.histretch_ex(img, "L", opencv32=True), orc.cvt_space(orc.cvt_space(img, 3), 3, True, opencv32=True))
+    assert np.array_equal(orc.histretch_ex(img, "L"), orc.cvt_space(orc.cvt_space(img, 3), 3, True))
+
+
 @pytest.mark.parametrize("name,theta,scale", [("in_PIS_T1A_259.jpg", 12, 1.05), ("in_PIS_T1A_259.jpg", 170, 1.0),
                                               ("in_BUL_T1A_0028.jpg", 40, 0.9)])
 def test_overlap_on_the_references_photographs(orc, name, theta, scale):
     """Real underwater texture instead of the synthetic scene.  PIS_T1A_259 is a RAW frame of turbid water (grey levels
-    81..146): with the fixed threshold the detector finds nothing and calcOverlap answers -2.0 whatever the motion; with the
-    contrast-relative threshold (the default) the overlap is found within the stated 0.01."""
+    81..146): with the fixed threshold (the default, as SURF's is fixed) the detector finds nothing and calcOverlap answers
+    -2.0 whatever the motion; with the contrast-relative threshold (the opt-in) the overlap is found within the stated 0.01."""
     key, cur, A = _real_photo_pair(name, theta, scale)
     truth, _ = orc.overlapArea(synth.to_working_homography(A, key.shape[1]), 640, 480)
-    r, info, _ = orc.calcOverlap(key, cur, 640, 480, seed=1)
+    r, info, _ = orc.calcOverlap(key, cur, 640, 480, seed=1, relative_threshold=True)
     assert abs(r - truth) <= 0.01 and info[3] >= 30, (r, truth, info)
     if name.startswith("in_PIS"):
-        rf, inf2, _ = orc.calcOverlap(key, cur, 640, 480, seed=1, fixed_threshold=True)
+        rf, inf2, _ = orc.calcOverlap(key, cur, 640, 480, seed=1)
         assert rf == -2.0 and inf2[0] == 0
 
 
 def test_overlap_noise_frames_do_not_match(orc):
-    """The contrast-relative threshold finds a few dozen "keypoints" in pure sensor noise (there is nothing else to find);
-    two independent noise frames must still come out as "not enough good matches" (-2.0), like under the fixed threshold."""
+    """Two independent frames of pure sensor noise come out as "not enough good matches" (-2.0) under the defaults (fixed
+    threshold: no keypoint at all).  The contrast-relative threshold finds a few dozen "keypoints" in the noise (there is
+    nothing else to find) and, now and then, four chance matches -- under the reference's ">= 4 good matches" rule those give
+    a bogus overlap value, which is what UWIP_OVERLAP_MIN6 is for: relative threshold + >= 6 inliers -> -2.0 again."""
     rng = np.random.default_rng(0)
     for mean, sd in ((20, 2), (128, 12)):
         a = np.clip(np.rint(rng.normal(mean, sd, (480, 854, 3))), 0, 255).astype(np.uint8)
         b = np.clip(np.rint(rng.normal(mean, sd, (480, 854, 3))), 0, 255).astype(np.uint8)
         assert orc.calcOverlap(a, b, 640, 480, seed=1)[0] == -2.0
-        assert orc.calcOverlap(a, b, 640, 480, seed=1, fixed_threshold=True)[0] == -2.0
+        assert orc.calcOverlap(a, b, 640, 480, seed=1, relative_threshold=True, min6=True)[0] == -2.0

@@ -166,8 +166,8 @@ def test_bench_stream_consecutive_frames_vs_truth(ctx, orc):
 
 def test_hazy_real_photograph_contrast_relative_threshold(ctx, orc):
     """The reference's raw turbid-water photograph PIS_T1A_259: device == oracle with the contrast-relative detector
-    threshold (keypoints, descriptors, ratio within 0.01 of the truth under yaw + zoom) and with the fixed one (no keypoint,
-    -2.0)."""
+    threshold (UWIP_OVERLAP_RELATIVE_THRESHOLD: keypoints, descriptors, ratio within 0.01 of the truth under yaw + zoom) and
+    with the fixed one, the default (no keypoint, -2.0); the two flags together are refused."""
     import sys, os
     sys.path.insert(0, os.path.dirname(__file__))
     from test_oracle_integer import _real_photo_pair
@@ -175,17 +175,24 @@ def test_hazy_real_photograph_contrast_relative_threshold(ctx, orc):
     key, cur, A = _real_photo_pair("in_PIS_T1A_259.jpg", 12, 1.05)
     truth, _ = orc.overlapArea(synth.to_working_homography(A, key.shape[1]), 640, 480)
     f = vs.Features(ctx, 2)
-    f.detect(_dev(np.stack([key, cur])))
+    f.detect(_dev(np.stack([key, cur])), relative_threshold=True)
     for s_, im in enumerate((key, cur)):
         kps, desc = f.download(s_)
-        ek, ed, _ = orc.detect_describe(orc.resize_gray(im))
+        ek, ed, _ = orc.detect_describe(orc.resize_gray(im), relative_threshold=True)
         assert len(kps) == len(ek) >= 60 and np.array_equal(kps["x"], ek["x"]) and np.array_equal(desc, ed)
     r = float(vs.match_pairs(ctx, f, f, [1], [0], 640, 480, seed=1)["ratio"].cpu()[0])
-    er, _, _ = orc.calcOverlap(key, cur, 640, 480, seed=1)
+    er, _, _ = orc.calcOverlap(key, cur, 640, 480, seed=1, relative_threshold=True)
     assert abs(r - er) <= 1e-6 and abs(r - truth) <= 0.01
-    f.detect(_dev(np.stack([key, cur])), fixed_threshold=True)
+    f.detect(_dev(np.stack([key, cur])))
     assert len(f.download(0)[0]) == 0
     assert float(vs.match_pairs(ctx, f, f, [1], [0], 640, 480, seed=1)["ratio"].cpu()[0]) == -2.0
+    from uwimageproc_amd import batch_of
+    import ctypes as C
+    b = batch_of(_dev(np.stack([key, cur])))
+    ctx.call("uwip_overlap_detect_ex", C.byref(b), f._h, 0, 2)            # UWIP_OVERLAP_FIXED_THRESHOLD: accepted, the default
+    assert len(f.download(0)[0]) == 0
+    with pytest.raises(Exception):
+        ctx.call("uwip_overlap_detect_ex", C.byref(b), f._h, 0, 2 | 16)
 
 
 def test_upright_descriptor_envelope(ctx, orc):
@@ -298,10 +305,11 @@ def test_resize_bgr_and_selector_on_1080p(ctx, orc):
     assert [(a, b) for a, b, _, _ in got] == exp and len(exp) >= 2, (got, exp)
 
 
-def test_reference_four_match_rule_flag(ctx, orc):
-    """UWIP_OVERLAP_MIN4 (uwip_overlap_match_ex): the reference takes any homography findHomography returns for >= 4 good
-    matches (videostrip.cpp:252-272); the default needs >= 6 inliers.  Four consistent matches + one outlier (+ one query the
-    reference's loop bound skips, B-12): -2.0 by default, the oracle's overlap under the flag."""
+def test_reference_four_match_rule_is_the_default(ctx, orc):
+    """The reference takes any homography findHomography returns for >= 4 good matches (videostrip.cpp:252-272): that is the
+    default of uwip_overlap_match (round 5); UWIP_OVERLAP_MIN6 (uwip_overlap_match_ex) asks for >= 6 inliers.  Four consistent
+    matches + one outlier (+ one query the reference's loop bound skips, B-12): the oracle's overlap by default, -2.0 under
+    the flag; UWIP_OVERLAP_MIN4 is still accepted and names the default; the two flags together are refused."""
     import ctypes as C
     rng = np.random.default_rng(11)
     n = 6
@@ -316,9 +324,17 @@ def test_reference_four_match_rule_flag(ctx, orc):
     f = vs.Features(ctx, 2)
     ctx.call("uwip_features_upload", f._h, 0, 360, 640, C.c_void_p(kq.ctypes.data), C.c_void_p(desc.ctypes.data), n)
     ctx.call("uwip_features_upload", f._h, 1, 360, 640, C.c_void_p(kt.ctypes.data), C.c_void_p(desc.ctypes.data), n)
-    r6 = vs.match_pairs(ctx, f, f, [0], [1], 640, 480, seed=1)
-    r4 = vs.match_pairs(ctx, f, f, [0], [1], 640, 480, seed=1, min4=True)
+    r4 = vs.match_pairs(ctx, f, f, [0], [1], 640, 480, seed=1)
+    r6 = vs.match_pairs(ctx, f, f, [0], [1], 640, 480, seed=1, min6=True)
     assert float(r6["ratio"].cpu()[0]) == -2.0
+    pq, pt = (C.c_int32 * 1)(0), (C.c_int32 * 1)(1)
+    rr = torch.empty(1, dtype=torch.float32, device="cuda")
+    args = (f._h, f._h, pq, pt, 1, 640, 480, 1)
+    ctx.call("uwip_overlap_match_ex", *args, 4, C.c_void_p(rr.data_ptr()), None, None, None, None)      # UWIP_OVERLAP_MIN4
+    ctx.sync()
+    assert float(rr.cpu()[0]) == float(r4["ratio"].cpu()[0])
+    with pytest.raises(Exception):
+        ctx.call("uwip_overlap_match_ex", *args, 4 | 8, C.c_void_p(rr.data_ptr()), None, None, None, None)
     idx, dist = orc.match_knn2(desc, desc)
     gq, gt = orc.ratio_test(idx, dist, n)
     assert len(gq) == 5                                       # the last query is skipped (videostrip.cpp:235)

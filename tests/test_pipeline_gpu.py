@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 def test_full_pipe_small_stream(orc):
     F, H, W = 3, 270, 480
     frames = synth.uw_stream(0, F, H, W)
-    pipe = FramePipe(0, F, H, W, video_size=(640, 480))
+    pipe = FramePipe(0, F, H, W, video_size=(640, 480), guard_s=True)
     src = torch.from_numpy(frames).cuda()
     pipe.stage_dehaze(src)
     torch.cuda.synchronize()
@@ -109,7 +109,7 @@ def test_config5_full_pipe_4k(orc):
     must equal the frames run one at a time."""
     F, H, W = 2, 2160, 3840
     frames = synth.uw_stream(0, F, H, W)
-    pipe = FramePipe(0, F, H, W)
+    pipe = FramePipe(0, F, H, W, guard_s=True)
     src = torch.from_numpy(frames).cuda()
     pipe.stage_dehaze(src)
     torch.cuda.synchronize()
@@ -135,7 +135,7 @@ def test_config5_full_pipe_4k(orc):
     assert abs(ratios[1] - er) <= 1e-6
     pipe.close()
     # one frame at a time
-    single = FramePipe(0, 1, H, W)
+    single = FramePipe(0, 1, H, W, guard_s=True)
     for f in range(F):
         o, r = single.run(src[f:f + 1])
         torch.cuda.synchronize()
@@ -165,7 +165,7 @@ def test_degenerate_frames_run_clean(kind):
     frames = np.stack([img, img])
     outs = []
     for _ in range(2):
-        pipe = FramePipe(0, 2, H, W)
+        pipe = FramePipe(0, 2, H, W, guard_s=True)
         o, r = pipe.run(torch.from_numpy(frames).cuda())
         torch.cuda.synchronize()
         outs.append((o.cpu().numpy().copy(), r.cpu().numpy().copy(), list(pipe.params)))
@@ -212,7 +212,7 @@ def test_host_buffer_front_end_equals_device_path():
     frames = [synth.uw_stream(10 * i, F, H, W) for i in range(2)]
     ref = []
     for i in range(2):
-        p = FramePipe(0, F, H, W, video_size=(640, 480))
+        p = FramePipe(0, F, H, W, video_size=(640, 480), guard_s=True)
         out, ratio = p.run(torch.from_numpy(frames[i]).cuda())
         torch.cuda.synchronize()
         ref.append((out.cpu().numpy().copy(), ratio.cpu().numpy().copy()))
@@ -221,7 +221,7 @@ def test_host_buffer_front_end_equals_device_path():
     pipes, bufs = [], []
     for i in range(2):
         with torch.cuda.stream(streams[i]):
-            pipes.append(FramePipe(0, F, H, W, video_size=(640, 480)))
+            pipes.append(FramePipe(0, F, H, W, video_size=(640, 480), guard_s=True))
         bufs.append(pipes[i].host_buffers())
         bufs[i][0][...] = frames[i]
         bufs[i][1][...] = 0
@@ -250,7 +250,7 @@ def test_host_buffer_front_end_prefetched_batches():
     overlap ratios carry across the batches as they do there."""
     F, H, W, NB = 2, 270, 480, 5
     batches = [synth.uw_stream(F * b, F, H, W) for b in range(NB)]
-    ref_pipe = FramePipe(0, F, H, W, video_size=(640, 480))
+    ref_pipe = FramePipe(0, F, H, W, video_size=(640, 480), guard_s=True)
     ref = []
     for b in range(NB):
         out, ratio = ref_pipe.run(torch.from_numpy(batches[b]).cuda())
@@ -258,7 +258,7 @@ def test_host_buffer_front_end_prefetched_batches():
         ref.append((out.cpu().numpy().copy(), ratio.cpu().numpy().copy()))
     ref_pipe.close()
     with torch.cuda.stream(torch.cuda.Stream()):
-        pipe = FramePipe(0, F, H, W, video_size=(640, 480))
+        pipe = FramePipe(0, F, H, W, video_size=(640, 480), guard_s=True)
     h_in = [pipe.ctx.host_alloc((F, H, W, 3)) for _ in range(NB)]
     h_out = [pipe.ctx.host_alloc((F, H, W, 3)) for _ in range(NB)]
     for b in range(NB):
@@ -288,7 +288,7 @@ def test_stream_driver_seam_rule_with_the_real_pipe():
     n, B, H, W = 7, 3, 216, 384
     frames = synth.uw_stream(0, n, H, W)
     def run(rank, world):
-        pipe = FramePipe(0, B, H, W, video_size=(640, 480))
+        pipe = FramePipe(0, B, H, W, video_size=(640, 480), guard_s=True)
         drv = stream.StreamDriver(n, rank, world, B, stream.pipe_process(pipe))
         outs = {}
         r, p = drv.run(lambda i: frames[i], sink=lambda i, f: outs.__setitem__(i, f.copy()))
@@ -303,3 +303,99 @@ def test_stream_driver_seam_rule_with_the_real_pipe():
     assert got_p == p1 and np.array_equal(np.array(got_r, np.float32), np.array(r1, np.float32))
     for i in range(n):
         assert np.array_equal(got_o[i], o1[i]), i
+
+
+def test_pipe_c_abi_reference_defaults_step_and_host_form(orc):
+    """uwip_pipe_* driven through ctypes alone (what a C / C++ integrator binds, include/uwip.h "the whole per-frame chain"):
+    with uwip_pipe_config_default -- the reference's rules: S unguarded, >= 4 good matches, fixed detector threshold -- two
+    steps through uwip_pipe_step equal the chain made by hand from the stage entry points (uwip_dehaze_histretch, uwip_bgr_to_v,
+    uwip_aclahe_auto_ex, uwip_hsv_replace_v, uwip_overlap_detect / _match with the feature-slot carry), and the same two
+    batches through uwip_pipe_step_host (frames AND ratios downloaded, tickets) give the same bytes."""
+    import ctypes as C
+    from uwimageproc_amd import Context, PipeConfig, batch_of
+    F, H, W = 3, 270, 480
+    ctx = Context(0)
+    l = ctx._l
+    cfg = PipeConfig()
+    assert l.uwip_pipe_config_default(C.byref(cfg), F, H, W) == 0
+    cfg.videoWidth, cfg.videoHeight = 640, 480
+    h = C.c_void_p()
+    ctx.call("uwip_pipe_create", C.byref(cfg), None, C.byref(h))
+
+    def pc(name, *a):
+        rc = getattr(l, name)(h, *a)
+        assert rc == 0, (name, rc, l.uwip_pipe_last_error(h))
+    batches = [torch.from_numpy(synth.uw_stream(F * b, F, H, W)).cuda() for b in range(2)]
+    outs = [torch.empty_like(batches[0]) for _ in range(2)]
+    ratios = [torch.empty(F, dtype=torch.float32, device="cuda") for _ in range(2)]
+    infos = [torch.zeros((F, 8), dtype=torch.int32, device="cuda") for _ in range(2)]
+    params = []
+    for b in range(2):
+        ib, ob = batch_of(batches[b]), batch_of(outs[b])
+        pc("uwip_pipe_step", C.byref(ib), C.byref(ob), C.c_void_p(ratios[b].data_ptr()), C.c_void_p(infos[b].data_ptr()))
+        bs, cl = (C.c_int32 * F)(), (C.c_int32 * F)()
+        pc("uwip_pipe_last_params", bs, cl)
+        params.append(list(zip(bs, cl)))
+    pc("uwip_pipe_sync")
+    # in place dehaze is refused, a wrong geometry too
+    ib = batch_of(batches[0])
+    assert l.uwip_pipe_step(h, C.byref(ib), C.byref(ib), C.c_void_p(ratios[0].data_ptr()), None) != 0
+    assert b"distinct" in l.uwip_pipe_last_error(h)
+    small = batch_of(batches[0][:2])
+    assert l.uwip_pipe_step(h, C.byref(small), C.byref(batch_of(outs[0][:2])), C.c_void_p(ratios[0].data_ptr()), None) != 0
+
+    # the same chain by hand
+    c2 = Context(0)
+    fh = C.c_void_p()
+    c2.call("uwip_features_create", F + 1, C.byref(fh))
+    v, vo = torch.empty((F, H, W), dtype=torch.uint8, device="cuda"), torch.empty((F, H, W), dtype=torch.uint8, device="cuda")
+    pq, pt = (C.c_int32 * F)(*range(1, F + 1)), (C.c_int32 * F)(*range(F))
+    for b in range(2):
+        o = torch.empty_like(batches[b])
+        r = torch.empty(F, dtype=torch.float32, device="cuda")
+        ib, ob, vb, vob = batch_of(batches[b]), batch_of(o), batch_of(v), batch_of(vo)
+        c2.call("uwip_dehaze_histretch", C.byref(ib), C.byref(ob), 15, 1, b"RGB", 2, 98, 0)         # UWIP_DEHAZE_FULL, unguarded
+        c2.call("uwip_bgr_to_v", C.byref(ob), C.byref(vb))
+        bs, cl = (C.c_int32 * F)(), (C.c_int32 * F)()
+        c2.call("uwip_aclahe_auto_ex", C.byref(vb), C.byref(vob), 0, 1, bs, cl)                     # PREFILTER, synchronous form
+        c2.call("uwip_hsv_replace_v", C.byref(ob), C.byref(vob), C.byref(ob))
+        if b == 0:
+            c2.call("uwip_overlap_detect", C.byref(batch_of(o[0:1])), fh, 0)
+        else:
+            c2.call("uwip_features_copy", fh, F, fh, 0)
+        c2.call("uwip_overlap_detect", C.byref(ob), fh, 1)
+        c2.call("uwip_overlap_match", fh, fh, pq, pt, F, 640, 480, 1, C.c_void_p(r.data_ptr()), None, None, None, None)
+        c2.sync()
+        assert torch.equal(o, outs[b]) and torch.equal(r, ratios[b]), b
+        assert params[b] == list(zip(bs, cl)), b
+    # frame 1 against frame 0 by the oracle, the reference's rule: the ratio of the device's own frames
+    o0 = outs[0].cpu().numpy()
+    er, _, _ = orc.calcOverlap(o0[0], o0[1], 640, 480, seed=1)
+    assert abs(float(ratios[0].cpu()[1]) - er) <= 1e-6
+    c2._l.uwip_features_destroy(fh)
+    c2.close()
+
+    # host-buffer form on a fresh pipe: same bytes, ratios downloaded too
+    h2 = C.c_void_p()
+    ctx.call("uwip_pipe_create", C.byref(cfg), None, C.byref(h2))
+    h_in = [ctx.host_alloc((F, H, W, 3)) for _ in range(2)]
+    h_out = [ctx.host_alloc((F, H, W, 3)) for _ in range(2)]
+    h_r = [ctx.host_alloc((F,), "float32") for _ in range(2)]
+    for b in range(2):
+        h_in[b][...] = batches[b].cpu().numpy()
+    t = (C.c_uint64 * 3)()
+    for b in range(2):
+        rc = l.uwip_pipe_step_host(h2, C.c_void_p(h_in[b].ctypes.data), C.c_void_p(h_out[b].ctypes.data), C.c_void_p(h_r[b].ctypes.data),
+                                   C.c_void_p(h_in[1].ctypes.data) if b == 0 else None, t)
+        assert rc == 0, l.uwip_pipe_last_error(h2)
+        assert t[0] and t[1] and t[2]
+        assert l.uwip_pipe_wait(h2, t[1]) == 0 and l.uwip_pipe_wait(h2, t[2]) == 0
+        assert np.array_equal(h_out[b], outs[b].cpu().numpy()), b
+        assert np.array_equal(h_r[b], ratios[b].cpu().numpy()), b
+    assert l.uwip_pipe_sync(h2) == 0
+    dv, df, dr = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    assert l.uwip_pipe_device_results(h2, C.byref(dv), C.byref(df), C.byref(dr), None) == 0 and dv.value and df.value and dr.value
+    for a in h_in + h_out + h_r:
+        ctx.host_free(a)
+    assert l.uwip_pipe_destroy(h2) == 0 and l.uwip_pipe_destroy(h) == 0
+    ctx.close()

@@ -27,6 +27,7 @@ import sys
 import time
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ["UWIP_TEST_HOOKS"] = "1"              # UWIP_DIAG_GF_ONLY is a measurement hook: dead in a product process
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

@@ -22,6 +22,20 @@ def short(name):
     return n.split("(")[0].split("<")[0]
 
 
+
+def tree_meta():
+    """what tree the counters were collected from: the digest runs here, right after gpurun has merged the CSVs of the tree it
+    snapshotted, so git HEAD + a dirty flag over the product sources say which tree that was (bench.py replays the figures of
+    this file as `traffic` and quotes this record next to them)"""
+    import subprocess, time
+    meta = {"collected": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime())}
+    try:
+        meta["git_head"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()
+        meta["dirty"] = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "uwimageproc_amd", "bench.py", "include"], text=True).strip())
+    except Exception:
+        meta["git_head"], meta["dirty"] = None, None
+    return meta
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
@@ -91,6 +105,7 @@ def main():
             if c in avg:
                 e[key] = avg[c] / a.frames
         ent[k] = e
+    d["_meta"] = tree_meta()
     json.dump(d, open(path, "w"), indent=1, sort_keys=True)
     for name in (f"bench_{a.tag}.json", f"bench4k_{a.tag}.json"):
         if os.path.exists(os.path.join(g, name)):

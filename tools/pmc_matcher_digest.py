@@ -36,6 +36,13 @@ try:
     out["unprofiled_run"] = {k: m[k] for k in ("avg_launch_ms", "achieved", "frac")}
 except Exception:
     pass
+try:
+    import subprocess, time
+    out["_meta"] = {"collected": time.strftime("%Y-%m-%dT%H:%M:%SZ", time.gmtime()),
+                    "git_head": subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip(),
+                    "dirty": bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "uwimageproc_amd", "bench.py", "include"], text=True).strip())}
+except Exception:
+    out["_meta"] = {}
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_matcher_pmc.json"), "w"), indent=1, sort_keys=True)
 with open(os.path.join(ROOT, "profiles", f"{tag}_matcher_counters.txt"), "w") as f:
     for k in sorted(avg):

@@ -6,6 +6,6 @@ the reference's host-side interfaces (same names, argument meaning and error
 behaviour) on top of that ABI; they hold no compute of their own and there is
 no CPU fallback.
 """
-from ._native import BatchU8, Context, Copier, UwipError, batch_of, device_count, lib  # noqa: F401
+from ._native import BatchU8, Context, Copier, PipeConfig, UwipError, batch_of, device_count, lib  # noqa: F401
 
-__all__ = ["BatchU8", "Context", "Copier", "UwipError", "batch_of", "device_count", "lib"]
+__all__ = ["BatchU8", "Context", "Copier", "PipeConfig", "UwipError", "batch_of", "device_count", "lib"]

@@ -41,6 +41,24 @@ class BatchU8(C.Structure):
     ]
 
 
+class PipeConfig(C.Structure):
+    """Mirror of ``uwip_pipe_config``."""
+
+    _fields_ = [
+        ("frames", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32),
+        ("letters", C.c_char * 16),
+        ("lo", C.c_int32), ("hi", C.c_int32),
+        ("w", C.c_int32),
+        ("dehaze_flags", C.c_uint32), ("histretch_flags", C.c_uint32),
+        ("residual_rule", C.c_int32),
+        ("aclahe_flags", C.c_uint32), ("detect_flags", C.c_uint32), ("match_flags", C.c_uint32),
+        ("videoWidth", C.c_int32), ("videoHeight", C.c_int32),
+        ("seed", C.c_uint32),
+        ("max_in_flight", C.c_int32),
+        ("d_staging", C.c_void_p),
+    ]
+
+
 _lib: Optional[C.CDLL] = None
 
 # name -> (restype, argtypes); every symbol include/uwip.h declares
@@ -82,6 +100,7 @@ SIGNATURES = {
     "uwip_histretch": (C.c_int, [_P, _B, C.c_char_p, C.c_int, C.c_int]),
     "uwip_histretch_ex": (C.c_int, [_P, _B, C.c_char_p, C.c_int, C.c_int, C.c_uint]),
     "uwip_cvtColor": (C.c_int, [_P, _B, _B, C.c_int, C.c_int]),
+    "uwip_cvtColor_ex": (C.c_int, [_P, _B, _B, C.c_int, C.c_int, C.c_int]),
     "uwip_bgr_to_v": (C.c_int, [_P, _B, _B]),
     "uwip_clahe": (C.c_int, [_P, _B, _B, C.c_double, C.c_int, C.c_int, C.c_int]),
     "uwip_clahe_per_frame": (C.c_int, [_P, _B, _B, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_int]),
@@ -119,6 +138,19 @@ SIGNATURES = {
                                         C.c_uint32, C.c_uint, _P, _P, _P, _P, _P]),
     "uwip_overlapArea": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "uwip_calcBlur": (C.c_int, [_P, _B, _P]),
+    "uwip_pipe_config_default": (C.c_int, [C.POINTER(PipeConfig), C.c_int, C.c_int, C.c_int]),
+    "uwip_pipe_staging_bytes": (C.c_size_t, [C.POINTER(PipeConfig)]),
+    "uwip_pipe_create": (C.c_int, [_P, C.POINTER(PipeConfig), _P, C.POINTER(_P)]),
+    "uwip_pipe_destroy": (C.c_int, [_P]),
+    "uwip_pipe_last_error": (C.c_char_p, [_P]),
+    "uwip_pipe_step": (C.c_int, [_P, _B, _B, _P, _P]),
+    "uwip_pipe_stages": (C.c_int, [_P, C.c_uint, _B, _B, _P, _P]),
+    "uwip_pipe_step_host": (C.c_int, [_P, _P, _P, _P, _P, C.POINTER(C.c_uint64)]),
+    "uwip_pipe_wait": (C.c_int, [_P, C.c_uint64]),
+    "uwip_pipe_sync": (C.c_int, [_P]),
+    "uwip_pipe_reset": (C.c_int, [_P]),
+    "uwip_pipe_last_params": (C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "uwip_pipe_device_results": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), C.POINTER(_P)]),
 }
 
 

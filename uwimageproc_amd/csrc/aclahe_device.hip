@@ -90,7 +90,8 @@ UWIP_API int uwip_aclahe_select_device(uwip_ctx *ctx, const float *d_entropy, in
     {
         uwip_kscope ks(ctx, "k_aclahe_choose");
         // a knee index >= 26 takes a degenerate fit: the tests force one to reach the exact block-size search
-        const char *fe = std::getenv("UWIP_ACLAHE_TEST_FORCE_CL");
+        // (a test hook: only in a process started with UWIP_TEST_HOOKS=1, uwip_internal.hpp)
+        const char *fe = uwip_test_hooks() ? std::getenv("UWIP_ACLAHE_TEST_FORCE_CL") : nullptr;
         const int force_d = fe && *fe ? std::atoi(fe) : -1;
         k_aclahe_choose<<<uwip_cdiv(frames, 64), 64, 0, ctx->stream>>>(d_entropy, knee, frames, d_par, force_d);
         UWIP_HIP(ctx, hipGetLastError());

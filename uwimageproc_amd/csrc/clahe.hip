@@ -1760,6 +1760,10 @@ UWIP_API int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const 
     UWIP_REQUIRE(ctx, (flags & ~(unsigned)(UWIP_ACLAHE_PREFILTER | UWIP_ACLAHE_HOST_SELECT | UWIP_ACLAHE_ASYNC)) == 0, "unknown flag");
     UWIP_REQUIRE(ctx, !(flags & UWIP_ACLAHE_ASYNC) || (!h_bs && !h_cl), "UWIP_ACLAHE_ASYNC: the parameters are fetched with uwip_aclahe_last_params");
     const int F = img->frames;
+    // a call that fails leaves "no parameters recorded" (not the previous call's): recorded only after the last launch succeeded
+    ctx->aclahe_last_n = 0;
+    ctx->aclahe_last_on_device = false;
+    ctx->aclahe_last_host.clear();
     // Where the choice is made.  Default: on the device (no table copy, no host computation: 0.25 CPU-seconds per 512-frame
     // step and rank otherwise) -- except for batches of a few frames, where latency is what matters (the paced 4K@60 stream
     // runs one frame per call): a curve takes one wavefront 1.3 ms on the device (a serial dependent chain of float64
@@ -1789,8 +1793,6 @@ UWIP_API int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const 
     float *extra = (float *)(h_par + 4 * F);
     double *clip = (double *)(extra + 5 * F);
     bool any = false;
-    ctx->aclahe_last_n = F;
-    ctx->aclahe_last_on_device = false;
     if (!host_select && (flags & UWIP_ACLAHE_ASYNC)) {
         // nothing comes back to the host: the choice (aclahe_device.hip) and the launch of the final CLAHE from the
         // device-side parameters (clahe_per_frame_device) are queued behind the sweep, and the call returns
@@ -1800,8 +1802,11 @@ UWIP_API int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const 
         if (rc) return rc;
         rc = aclahe_exact_bs_device(ctx, src, d_par, residual_rule);
         if (rc) return rc;
+        rc = clahe_per_frame_device(ctx, img, dst, d_par, residual_rule);
+        if (rc) return rc;
+        ctx->aclahe_last_n = F;
         ctx->aclahe_last_on_device = true;
-        return clahe_per_frame_device(ctx, img, dst, d_par, residual_rule);
+        return UWIP_OK;
     }
     if (!host_select) {
         // the choice on the device (aclahe_device.hip): only {BS, CL, need} per frame come back -- the launch geometry of
@@ -1857,17 +1862,21 @@ UWIP_API int uwip_aclahe_auto_ex(uwip_ctx *ctx, const uwip_batch_u8 *img, const 
     for (int f = 0; f < F; ++f) clip[f] = (double)cl[f];
     if (h_bs) for (int f = 0; f < F; ++f) h_bs[f] = bs[f];
     if (h_cl) for (int f = 0; f < F; ++f) h_cl[f] = cl[f];
+    rc = uwip_clahe_per_frame(ctx, img, dst, clip, bs, residual_rule);
+    if (rc) return rc;
     ctx->aclahe_last_host.resize(2 * (size_t)F);
     for (int f = 0; f < F; ++f) { ctx->aclahe_last_host[2 * f] = bs[f]; ctx->aclahe_last_host[2 * f + 1] = cl[f]; }
-    return uwip_clahe_per_frame(ctx, img, dst, clip, bs, residual_rule);
+    ctx->aclahe_last_n = F;
+    return UWIP_OK;
 }
 
 // the parameters of the most recent uwip_aclahe_auto_ex on this context (waits for the stream when they are still on the device)
 UWIP_API int uwip_aclahe_last_params(uwip_ctx *ctx, int32_t *h_bs, int32_t *h_cl, int frames)
 {
     if (int rc_e = uwip_enter(ctx)) return rc_e;
+    if (frames == 0 && ctx->aclahe_last_n == 0) return UWIP_OK;
+    UWIP_REQUIRE(ctx, ctx->aclahe_last_n > 0, "no parameters recorded (no uwip_aclahe_auto_ex yet, or the last one failed)");
     UWIP_REQUIRE(ctx, frames == ctx->aclahe_last_n, "frame count differs from the last uwip_aclahe_auto_ex");
-    if (frames == 0) return UWIP_OK;
     UWIP_REQUIRE(ctx, h_bs && h_cl, "null output");
     if (ctx->aclahe_last_on_device) {
         const int32_t *d_par = (const int32_t *)uwip_ws(ctx, "auto.par", sizeof(int32_t) * 4 * (size_t)frames);

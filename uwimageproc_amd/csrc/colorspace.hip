@@ -131,6 +131,11 @@ struct LabTabs {
     const float *invgamma;      // sRGBInvGammaTab[1024 * 4] (cubic spline coefficients)
     int C[9];                   // forward coefficients for B, G, R order
     float K[9];                 // inverse coefficients: rows give R, G, B from (x, y, z)
+    // OpenCV 3.4.x: Lab2RGBinteger (bit-exact integer inverse, the default of cv::cvtColor for 8-bit Lab since 3.4.0)
+    const uint16_t *yf;         // LabToYF_b[256 * 2] = (y, ify) per L, base 2^14
+    const uint16_t *invgamma_b; // sRGBInvGammaTab_b[4096]
+    int Ki[9];                  // cvRound(2^12 * XYZ2sRGB_D65 * D65): rows give R, G, B
+    int rule;                   // 0 = OpenCV 3.4.x (integer inverse), 1 = OpenCV 3.2 (float inverse through the spline)
 };
 __device__ __forceinline__ int descale_n(int x, int n) { return (x + (1 << (n - 1))) >> n; }
 __device__ __forceinline__ void bgr2lab_u8(int b, int g, int r, const LabTabs &T, int &L, int &A, int &Bq)
@@ -176,6 +181,30 @@ __device__ __forceinline__ void lab2bgr_u8(int Li, int Ai, int Bi, const LabTabs
     B = (int)sat_u8_rne(bo * 255.f); G = (int)sat_u8_rne(go * 255.f); R = (int)sat_u8_rne(ro * 255.f);
 }
 
+// Lab2RGBinteger::process of OpenCV 3.4.x (imgproc/src/color_lab.cpp; restated, parity unpinned): y and fy from a table of
+// L, fx = fy + a / 500 and fz = fy - b / 200 in base 2^14 through the multiply-shift forms OpenCV uses, the cube (or the
+// linear branch below 6/29) in integer arithmetic -- abToXZ_b is a table there, computed here: its entries are two integer
+// divisions -- the 3x3 matrix in 2^12 fixed point, descale by 14, the inverse sRGB gamma from a 4096-entry table.
+__device__ __forceinline__ int lab_ab_to_xz(int i)
+{
+    constexpr int BASE = 1 << 14;
+    // C division (truncation towards zero) as in initLabTabs: i may be negative on the linear branch
+    return i <= 3390 ? i * 108 / 841 - BASE * 16 / 116 * 108 / 841 : i * i / BASE * i / BASE;
+}
+__device__ __forceinline__ void lab2bgr_int_u8(int LL, int aa, int bb, const LabTabs &T, int &B, int &G, int &R)
+{
+    constexpr int BASE = 1 << 14;
+    const int y = T.yf[LL * 2], ify = T.yf[LL * 2 + 1];
+    const int adiv = ((5 * aa * 53687 + (1 << 7)) >> 13) - 128 * BASE / 500;
+    const int bdiv = ((bb * 41943 + (1 << 4)) >> 9) - 128 * BASE / 200 + 1;
+    const int x = lab_ab_to_xz(ify + adiv), z = lab_ab_to_xz(ify - bdiv);
+    int ro = descale_n(T.Ki[0] * x + T.Ki[1] * y + T.Ki[2] * z, 14);
+    int go = descale_n(T.Ki[3] * x + T.Ki[4] * y + T.Ki[5] * z, 14);
+    int bo = descale_n(T.Ki[6] * x + T.Ki[7] * y + T.Ki[8] * z, 14);
+    ro = max(0, min(4095, ro)); go = max(0, min(4095, go)); bo = max(0, min(4095, bo));
+    R = sat8(T.invgamma_b[ro]); G = sat8(T.invgamma_b[go]); B = sat8(T.invgamma_b[bo]);
+}
+
 // space: 1 HSV, 2 HLS, 3 Lab, 4 YCrCb (numSpace, preprocessing.cpp:155-160); dir: 0 BGR -> space, 1 space -> BGR,
 // 2 the 8-bit round trip in one pass (the as-written letters)
 template <int SPACE>
@@ -199,7 +228,7 @@ __global__ __launch_bounds__(256) void k_cvt_space(const uint8_t *__restrict__ s
         if (dir != 0) {           // inverse
             if (SPACE == 1) hsv2bgr_u8(a, b, c, p, q, r);
             if (SPACE == 2) hls2bgr_u8(a, b, c, p, q, r);
-            if (SPACE == 3) lab2bgr_u8(a, b, c, T, p, q, r);
+            if (SPACE == 3) { if (T.rule == 0) lab2bgr_int_u8(a, b, c, T, p, q, r); else lab2bgr_u8(a, b, c, T, p, q, r); }
             if (SPACE == 4) ycc2bgr_u8(a, b, c, p, q, r);
             a = p; b = q; c = r;
         }
@@ -228,6 +257,35 @@ void spline_build(const std::vector<float> &f, int n, std::vector<float> &tab)
     }
 }
 
+// The two tables of Lab2RGBinteger (OpenCV 3.4.x initLabTabs).  OpenCV builds them with its softfloat class -- IEEE float32
+// operations, each correctly rounded -- which plain float arithmetic is, this file being compiled without contraction or
+// fast-math; cvRound = round half to even = lrintf; pow is libm's powf (softfloat's own pow may differ from it in the last
+// place, which shows only where 255 * x lands within an ulp of a rounding tie).
+void lab_int_tables(uint16_t *yf, uint16_t *ig)
+{
+    const int BASE = 1 << 14;
+    for (int i = 0; i < 256; ++i) {
+        long y, ify;
+        if (i <= 20) {                                       // 8 * 255 / 100 = 20.4
+            y = std::lrintf((float)(i * BASE * 20 * 9) / (float)(17 * 29 * 29 * 29));
+            ify = std::lrintf((float)BASE * ((float)16 / (float)116 + (float)(i * 5) / (float)(3 * 17 * 29)));
+        } else {
+            const float fy = (float)(i * 100 * BASE) / (float)(255 * 116) + (float)(16 * BASE) / (float)116;
+            ify = std::lrintf(fy);
+            y = std::lrintf(fy * fy * fy / (float)(BASE * BASE));
+        }
+        yf[i * 2] = (uint16_t)y;
+        yf[i * 2 + 1] = (uint16_t)ify;
+    }
+    const float thr = (float)7827 / (float)2500000, lowScale = (float)323 / (float)25, power = (float)12 / (float)5,
+                xshift = (float)11 / (float)200;
+    for (int i = 0; i < 4096; ++i) {
+        const float x = (1.0f / 4096.0f) * (float)i;
+        const float g = x <= thr ? x * lowScale : std::pow(x, 1.0f / power) * (1.0f + xshift) - xshift;
+        ig[i] = (uint16_t)std::lrintf(255.0f * g);
+    }
+}
+
 int lab_tables(uwip_ctx *ctx, LabTabs *T)
 {
     static const float sRGB2XYZ_D65[9] = {0.412453f, 0.357580f, 0.180423f, 0.212671f, 0.715160f, 0.072169f, 0.019334f, 0.119193f, 0.950227f};
@@ -235,7 +293,8 @@ int lab_tables(uwip_ctx *ctx, LabTabs *T)
     static const float D65[3] = {0.950456f, 1.f, 1.088754f};
     const void *d = uwip_table_find(ctx, "lab.tables", nullptr);
     if (!d) {
-        std::vector<uint8_t> buf(512 + 6144 + 16384);
+        std::vector<uint8_t> buf(512 + 6144 + 16384 + 1024 + 8192);
+        lab_int_tables((uint16_t *)(buf.data() + 512 + 6144 + 16384), (uint16_t *)(buf.data() + 512 + 6144 + 16384 + 1024));
         uint16_t *g = (uint16_t *)buf.data(), *cb = (uint16_t *)(buf.data() + 512);
         for (int i = 0; i < 256; ++i) {
             const float x = (float)i * (1.f / 255.f);
@@ -260,6 +319,15 @@ int lab_tables(uwip_ctx *ctx, LabTabs *T)
     T->gamma = (const uint16_t *)d;
     T->cbrt = (const uint16_t *)((const uint8_t *)d + 512);
     T->invgamma = (const float *)((const uint8_t *)d + 512 + 6144);
+    T->yf = (const uint16_t *)((const uint8_t *)d + 512 + 6144 + 16384);
+    T->invgamma_b = (const uint16_t *)((const uint8_t *)d + 512 + 6144 + 16384 + 1024);
+    {
+        // cvRound(lshift * c * whitePt) in softdouble = double arithmetic here
+        static const double X2R[9] = {3.240479, -1.53715, -0.498535, -0.969256, 1.875991, 0.041556, 0.055648, -0.204043, 1.057311};
+        static const double W[3] = {0.950456, 1., 1.088754};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) T->Ki[j * 3 + i] = (int)std::lrint(4096.0 * X2R[j * 3 + i] * W[i]);
+    }
     const float scale[3] = {(float)(1 << 12) / D65[0], (float)(1 << 12), (float)(1 << 12) / D65[2]};
     for (int i = 0; i < 3; ++i) {           // pixel order B, G, R: blueIdx = 0
         T->C[i * 3 + 2] = (int)std::lrintf(sRGB2XYZ_D65[i * 3] * scale[i]);
@@ -290,15 +358,16 @@ const int *hsv_tables2(uwip_ctx *ctx)
 
 // cv::cvtColor(src, dst, COLOR_BGR2{HSV,HLS,Lab,YCrCb}) (dir 0), the matching ...2BGR (dir 1) or both in one pass
 // (dir 2), 8UC3; space = numSpace's index 1..4.  dst may alias src.
-int uwip_cvt_space_internal(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int space, int dir)
+int uwip_cvt_space_internal(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int space, int dir, int opencv_rule)
 {
+    UWIP_REQUIRE(ctx, opencv_rule == 0 || opencv_rule == 1, "opencv_rule must be 0 (OpenCV 3.4.x) or 1 (OpenCV 3.2)");
     UWIP_REQUIRE(ctx, space >= 1 && space <= 4 && dir >= 0 && dir <= 2, "bad colour space / direction");
     UWIP_REQUIRE(ctx, src->rows == dst->rows && src->cols == dst->cols && src->frames == dst->frames, "src/dst shape mismatch");
     if (uwip_batch_empty(src)) return UWIP_OK;
     UWIP_REQUIRE(ctx, src->rows <= 65535 && src->frames <= 65535, "too many rows/frames for one launch");
     LabTabs T{};
     const int *hsv = nullptr;
-    if (space == 3) { int rc = lab_tables(ctx, &T); if (rc) return rc; }
+    if (space == 3) { int rc = lab_tables(ctx, &T); if (rc) return rc; T.rule = opencv_rule; }
     if (space == 1) { hsv = hsv_tables2(ctx); if (!hsv) return UWIP_ERR_NOMEM; }
     const dim3 grid(std::min(uwip_cdiv(src->cols, 256), 32u), (unsigned)src->rows, (unsigned)src->frames);
     uwip_kscope ks(ctx, "k_cvt_space");
@@ -313,11 +382,16 @@ int uwip_cvt_space_internal(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_
     return UWIP_OK;
 }
 
-UWIP_API int uwip_cvtColor(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int space, int to_bgr)
+UWIP_API int uwip_cvtColor_ex(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int space, int to_bgr, int opencv_rule)
 {
     int rc = uwip_check_batch(ctx, src, 3);
     if (rc) return rc;
     rc = uwip_check_batch(ctx, dst, 3);
     if (rc) return rc;
-    return uwip_cvt_space_internal(ctx, src, dst, space, to_bgr ? 1 : 0);
+    return uwip_cvt_space_internal(ctx, src, dst, space, to_bgr ? 1 : 0, opencv_rule);
+}
+
+UWIP_API int uwip_cvtColor(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int space, int to_bgr)
+{
+    return uwip_cvtColor_ex(ctx, src, dst, space, to_bgr, 0);
 }

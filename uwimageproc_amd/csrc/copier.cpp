@@ -67,13 +67,33 @@ struct uwip_copier {
             Request r;
             bool ready = false;
             {
-                std::unique_lock<std::mutex> lk(L.mu);
-                L.cv_work.wait(lk, [&] { return L.stop || !L.q.empty(); });
-                if (L.q.empty()) return;                    // stop requested and nothing left
-                // the first queued request that can run now; none: the head, and sleep on its dependency
+                // The first queued request that can run now; none: the head, and sleep on its dependency.  A request never
+                // overtakes an earlier one when one of the two WRITES bytes the other touches (an upload with after = NULL into
+                // a buffer an earlier upload with a dependency still targets; a download into a host buffer an earlier one
+                // still fills): those stay FIFO; two reads of one buffer do not order each other.  The dependency events are queried on a snapshot, outside the lane's mutex (submitters only append).
+                std::vector<Request> snap;
+                {
+                    std::unique_lock<std::mutex> lk(L.mu);
+                    L.cv_work.wait(lk, [&] { return L.stop || !L.q.empty(); });
+                    if (L.q.empty()) return;                    // stop requested and nothing left
+                    snap.assign(L.q.begin(), L.q.end());
+                }
+                auto overlaps = [](const void *a, size_t an, const void *b, size_t bn) {
+                    const char *x = (const char *)a, *y = (const char *)b;
+                    return x < y + bn && y < x + an;
+                };
+                uint64_t pick_seq = snap[0].seq;
+                for (size_t i = 0; i < snap.size(); ++i) {
+                    bool blocked = false;
+                    for (size_t j = 0; j < i && !blocked; ++j)
+                        blocked = overlaps(snap[i].dst, snap[i].bytes, snap[j].dst, snap[j].bytes) ||
+                                  overlaps(snap[i].dst, snap[i].bytes, snap[j].src, snap[j].bytes) || overlaps(snap[i].src, snap[i].bytes, snap[j].dst, snap[j].bytes);
+                    if (blocked) continue;
+                    if (!snap[i].after || hipEventQuery(snap[i].after) == hipSuccess) { pick_seq = snap[i].seq; ready = true; break; }
+                }
+                std::lock_guard<std::mutex> lk(L.mu);
                 size_t pick = 0;
-                for (size_t i = 0; i < L.q.size(); ++i)
-                    if (!L.q[i].after || hipEventQuery(L.q[i].after) == hipSuccess) { pick = i; ready = true; break; }
+                while (pick < L.q.size() && L.q[pick].seq != pick_seq) ++pick;      // this lane's thread is the only remover
                 r = L.q[pick];
                 L.q.erase(L.q.begin() + (std::ptrdiff_t)pick);
             }

@@ -751,11 +751,11 @@ int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t 
     UWIP_REQUIRE(ctx, (uint64_t)uwip_cdiv(W, 256 - 2 * r) * 16 * F * np < (1ull << 31) && (uint64_t)uwip_cdiv(W, 256 - 2 * r) * (2 * r + 1) * F * np < (1ull << 31), "too many blocks for one launch");
     UWIP_REQUIRE(ctx, (uint64_t)256 * (2 * r + 1) * 65025ull < (1ull << 32), "window too large for the exact integer guide sums");
     const int D = 2 * r + 1;
-    // UWIP_DIAG_GF_ONLY=solve | final (read at every call): launch only that kernel of the pair, the other one's output being
+    // UWIP_DIAG_GF_ONLY=solve | final (read at every call, in a process started with UWIP_TEST_HOOKS=1 only): launch only that kernel of the pair, the other one's output being
     // whatever the workspace holds from an earlier complete call.  A MEASUREMENT hook (tools/corun_matrix.py runs the two
     // kernels against each other and against the sweep on separate streams); results of such a call are meaningless.
     int diag_only = 0;
-    if (const char *e = getenv("UWIP_DIAG_GF_ONLY")) diag_only = e[0] == 's' ? 1 : (e[0] == 'f' ? 2 : 0);
+    if (const char *e = uwip_test_hooks() ? getenv("UWIP_DIAG_GF_ONLY") : nullptr) diag_only = e[0] == 's' ? 1 : (e[0] == 'f' ? 2 : 0);
     // four adjacent columns of a lane are one aligned vector access when everything is a multiple of 4
     const bool vec = (W % 4 == 0) && (r % 4 == 0) && (step % 4 == 0) && (fs % 4 == 0) && (((uintptr_t)guide) % 4 == 0) &&
                      (((uintptr_t)P | (uintptr_t)Q | (uintptr_t)AB) % 16 == 0);

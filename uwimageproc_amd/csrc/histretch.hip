@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256) void k_ycrcb_roundtrip(uint8_t *__restrict__ i
 }
 }  // namespace
 
-int uwip_cvt_space_internal(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int space, int dir);   // colorspace.hip
+int uwip_cvt_space_internal(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch_u8 *dst, int space, int dir, int opencv_rule);   // colorspace.hip
 
 uint32_t *uwip_histretch_hist_ws(uwip_ctx *ctx, const uwip_batch_u8 *img)
 {
@@ -468,8 +468,9 @@ int uwip_histretch_internal(uwip_ctx *ctx, const uwip_batch_u8 *img, const char 
     int rc = uwip_check_batch(ctx, img, 3);
     if (rc) return rc;
     UWIP_REQUIRE(ctx, letters != nullptr, "null letters");
-    UWIP_REQUIRE(ctx, (flags & ~(unsigned)UWIP_HISTRETCH_FIXED_ORDER) == 0, "unknown flag");
+    UWIP_REQUIRE(ctx, (flags & ~(unsigned)(UWIP_HISTRETCH_FIXED_ORDER | UWIP_HISTRETCH_OPENCV32)) == 0, "unknown flag");
     const bool fixed = (flags & UWIP_HISTRETCH_FIXED_ORDER) != 0;
+    const int cv_rule = (flags & UWIP_HISTRETCH_OPENCV32) ? 1 : 0;        // Lab -> BGR: 3.4.x integer form / 3.2 float form
     // Runs of BGR letters are composed into one LUT pass.  A letter of another colour space is, as written in the
     // reference (histretch.cpp:230-241), the 8-bit colour round trip of the image: the stretch goes to a
     // split copy and cvtColor(dst -> src) converts the unstretched planes back before the merge.  With
@@ -500,13 +501,13 @@ int uwip_histretch_internal(uwip_ctx *ctx, const uwip_batch_u8 *img, const char 
             tmp.data = uwip_ws(ctx, "histretch.space", (size_t)img->rows * img->cols * 3 * img->frames);
             if (!tmp.data) return UWIP_ERR_NOMEM;
             tmp.step = (size_t)img->cols * 3; tmp.frame_stride = tmp.step * img->rows;
-            rc = uwip_cvt_space_internal(ctx, img, &tmp, sp, 0);                 // cvtColor(src, dst, BGR2xxx)   :232
+            rc = uwip_cvt_space_internal(ctx, img, &tmp, sp, 0, cv_rule);                 // cvtColor(src, dst, BGR2xxx)   :232
             if (rc) return rc;
             LetterList one{};
             one.n = 1; one.plane[0] = (int8_t)uwip_numChannel(*c);
             rc = stretch_planes(ctx, &tmp, one, lo, hi);                         // split / imgChannelStretch / merge   :234-236,240
             if (rc) return rc;
-            rc = uwip_cvt_space_internal(ctx, &tmp, img, sp, 1);                 // cvtColor(dst, src, xxx2BGR) AFTER the merge
+            rc = uwip_cvt_space_internal(ctx, &tmp, img, sp, 1, cv_rule);                 // cvtColor(dst, src, xxx2BGR) AFTER the merge
             if (rc) return rc;
         } else if (sp == 1) {
             rc = uwip_hsv_roundtrip(ctx, img);
@@ -518,7 +519,7 @@ int uwip_histretch_internal(uwip_ctx *ctx, const uwip_batch_u8 *img, const char 
                 (uint8_t *)img->data, img->step, img->frame_stride, img->rows, img->cols);
             UWIP_HIP(ctx, hipGetLastError());
         } else {
-            rc = uwip_cvt_space_internal(ctx, img, img, sp, 2);                  // HLS / Lab: the 8-bit round trip
+            rc = uwip_cvt_space_internal(ctx, img, img, sp, 2, cv_rule);                  // HLS / Lab: the 8-bit round trip
             if (rc) return rc;
         }
     }

@@ -28,8 +28,10 @@ constexpr int DESC_BYTES = 64;     // packed bits
 constexpr int DESC_K = 512;        // unpacked 0/1 bytes for the i8 MFMA
 constexpr int BORDER = 8;
 constexpr float DTHRESH = 0.001f;
-constexpr int MIN_INLIERS = 6;       // default: a homography supported by fewer inliers is none (-2.0): four chance matches always fit one;
-                                     // UWIP_OVERLAP_MIN4 (uwip_overlap_match_ex) lowers it to the reference's 4 (videostrip.cpp:252-272)
+constexpr int MIN_INLIERS = 4;       // default = the reference's rule: whatever findHomography returns for >= 4 good matches
+                                     // (videostrip.cpp:252-272), i.e. any hypothesis with >= 4 inliers
+constexpr int MIN_INLIERS_STRICT = 6;   // UWIP_OVERLAP_MIN6 (uwip_overlap_match_ex): fewer inliers = no homography (-2.0): four chance
+                                        // matches always fit one
 constexpr float KC_REF = 0.5f;       // contrast factor at and above which the detector threshold is DTHRESH itself
 constexpr int RANSAC_ITERS = 512;
 constexpr int TW = 640, TH = 480;  // TARGET_WIDTH / TARGET_HEIGHT (videostrip.hpp:48-49)
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(256) void k_ov_ldet(const float2 *__restrict__ Lxy,
 // Ldet: [NLEV][F][h][w] (each level a dense batch); cand: [F][NLEV][h][w], response or 0
 // The detector threshold is relative to the frame's contrast factor k (det of the Hessian scales with contrast squared;
 // raw frames of turbid water have no response above a fixed 1e-3): DTHRESH * min(1, (k / KC_REF)^2), in the oracle's
-// operations; `fixed` keeps DTHRESH (UWIP_OVERLAP_FIXED_THRESHOLD).
+// operations (UWIP_OVERLAP_RELATIVE_THRESHOLD); `fixed` keeps DTHRESH (the default).
 // One block = a 64 x 8 tile of ALL levels: the four level tiles + 1 halo pixel are staged in LDS once (coalesced rows), and
 // every comparison of the 3 x 3 x 3 test and the sub-pixel check reads LDS -- the dense map of every level is read once
 // (x 1.29 for the halo) instead of once plus 26 scattered neighbour loads wherever any lane of a wave passes the threshold.
@@ -2024,7 +2026,9 @@ UWIP_API int uwip_overlap_detect_ex(uwip_ctx *ctx, const uwip_batch_u8 *frames, 
 {
     int rc = uwip_check_batch(ctx, frames, 0);
     if (rc) return rc;
-    UWIP_REQUIRE(ctx, (flags & ~(unsigned)(UWIP_OVERLAP_UPRIGHT | UWIP_OVERLAP_FIXED_THRESHOLD)) == 0, "unknown flag");
+    UWIP_REQUIRE(ctx, (flags & ~(unsigned)(UWIP_OVERLAP_UPRIGHT | UWIP_OVERLAP_FIXED_THRESHOLD | UWIP_OVERLAP_RELATIVE_THRESHOLD)) == 0, "unknown flag");
+    UWIP_REQUIRE(ctx, (flags & (UWIP_OVERLAP_FIXED_THRESHOLD | UWIP_OVERLAP_RELATIVE_THRESHOLD)) != (UWIP_OVERLAP_FIXED_THRESHOLD | UWIP_OVERLAP_RELATIVE_THRESHOLD),
+                 "UWIP_OVERLAP_FIXED_THRESHOLD and UWIP_OVERLAP_RELATIVE_THRESHOLD exclude each other");
     UWIP_REQUIRE(ctx, feats != nullptr && feats->ctx == ctx, "feature set belongs to another context");
     UWIP_REQUIRE(ctx, first_slot >= 0 && first_slot + frames->frames <= feats->capacity, "feature set too small");
     if (frames->frames == 0) return UWIP_OK;
@@ -2059,7 +2063,7 @@ UWIP_API int uwip_overlap_detect_ex(uwip_ctx *ctx, const uwip_batch_u8 *frames, 
     feats->w = w; feats->h = h;
     feats->frames = std::max(feats->frames, first_slot + F);
     return detect_describe(ctx, W, F, h, w, feats, first_slot, (flags & UWIP_OVERLAP_UPRIGHT) ? 1 : 0,
-                           (flags & UWIP_OVERLAP_FIXED_THRESHOLD) ? 1 : 0);
+                           (flags & UWIP_OVERLAP_RELATIVE_THRESHOLD) ? 0 : 1);
 }
 
 // tap for tests: one slot's keypoints / packed descriptors to the host
@@ -2175,8 +2179,9 @@ UWIP_API int uwip_overlap_match_ex(uwip_ctx *ctx, const uwip_features *fq, const
                                    float *d_ratio, int32_t *d_info, double *d_H, int32_t *d_match_idx, int32_t *d_match_dist)
 {
     if (int rc_e = uwip_enter(ctx)) return rc_e;
-    UWIP_REQUIRE(ctx, (flags & ~(unsigned)UWIP_OVERLAP_MIN4) == 0, "unknown flag");
-    const int min_inliers = (flags & UWIP_OVERLAP_MIN4) ? 4 : MIN_INLIERS;
+    UWIP_REQUIRE(ctx, (flags & ~(unsigned)(UWIP_OVERLAP_MIN4 | UWIP_OVERLAP_MIN6)) == 0, "unknown flag");
+    UWIP_REQUIRE(ctx, (flags & (UWIP_OVERLAP_MIN4 | UWIP_OVERLAP_MIN6)) != (UWIP_OVERLAP_MIN4 | UWIP_OVERLAP_MIN6), "UWIP_OVERLAP_MIN4 and UWIP_OVERLAP_MIN6 exclude each other");
+    const int min_inliers = (flags & UWIP_OVERLAP_MIN6) ? MIN_INLIERS_STRICT : MIN_INLIERS;
     UWIP_REQUIRE(ctx, fq && ft && fq->ctx == ctx && ft->ctx == ctx, "bad feature sets");
     UWIP_REQUIRE(ctx, npairs >= 0 && npairs <= 65535, "npairs out of range");
     if (npairs == 0) return UWIP_OK;

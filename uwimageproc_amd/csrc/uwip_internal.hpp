@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -112,6 +113,13 @@ bool uwip_gf_pu8_ok(const uint8_t *guide, size_t step, size_t fs, const uint8_t 
 int uwip_gf_wave_strip(uwip_ctx *ctx, const uint8_t *guide, size_t step, size_t fs, const int *gnorm, int gstride,
                        const double *P, double *Q, double *AB, int F, int np, int H, int W, int r, double eps,
                        const uwip_gf_pu8 *pu8 = nullptr, uwip_gf_recover *rec = nullptr);
+// Test / measurement hooks (UWIP_ACLAHE_TEST_FORCE_CL, UWIP_DIAG_GF_ONLY) are dead unless the process was started with
+// UWIP_TEST_HOOKS=1 in its environment: read ONCE, at the first call; a product process never looks at the hook variables.
+inline bool uwip_test_hooks()
+{
+    static const bool on = [] { const char *e = std::getenv("UWIP_TEST_HOOKS"); return e && *e == '1'; }();
+    return on;
+}
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (context, kernel)
 int uwip_lds_optin(uwip_ctx *ctx, const char *name, const void *func, size_t bytes);
 

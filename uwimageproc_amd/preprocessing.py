@@ -50,20 +50,22 @@ def imgChannelStretch(ctx: Context, imgOriginal: torch.Tensor, imgStretched: tor
 
 
 def histretch(ctx: Context, src: torch.Tensor, cChannel: str, min_percent: int = 2, max_percent: int = 98,
-              fixed_order: bool = False) -> None:
+              fixed_order: bool = False, opencv32: bool = False) -> None:
     """histretch.cpp:217-254 (CPU branch) on BGR frames, in place.  fixed_order=True keeps the stretch of the
-    non-BGR letters (merge before converting back) instead of the reference's as-written round trip (B-3)."""
+    non-BGR letters (merge before converting back) instead of the reference's as-written round trip (B-3); opencv32=True
+    converts Lab back to BGR as OpenCV 3.2 does (float form) instead of 3.4.x (integer form, the default)."""
     b = batch_of(src)
     torch.cuda.current_stream(src.device).synchronize()
-    ctx.call("uwip_histretch_ex", C.byref(b), cChannel.encode(), int(min_percent), int(max_percent), 1 if fixed_order else 0)
+    ctx.call("uwip_histretch_ex", C.byref(b), cChannel.encode(), int(min_percent), int(max_percent), (1 if fixed_order else 0) | (2 if opencv32 else 0))
     ctx.sync()
 
 
-def cvtColor(ctx: Context, src: torch.Tensor, space: int, to_bgr: bool = False) -> torch.Tensor:
-    """cv::cvtColor(src, COLOR_BGR2{HSV,HLS,Lab,YCrCb}) / the inverse, 8UC3; space = numSpace's index 1..4."""
+def cvtColor(ctx: Context, src: torch.Tensor, space: int, to_bgr: bool = False, opencv32: bool = False) -> torch.Tensor:
+    """cv::cvtColor(src, COLOR_BGR2{HSV,HLS,Lab,YCrCb}) / the inverse, 8UC3; space = numSpace's index 1..4; opencv32: the
+    Lab inverse of OpenCV 3.2 (float) instead of 3.4.x (integer)."""
     dst = torch.empty_like(src)
     sb, db = batch_of(src), batch_of(dst)
     torch.cuda.current_stream(src.device).synchronize()
-    ctx.call("uwip_cvtColor", C.byref(sb), C.byref(db), int(space), 1 if to_bgr else 0)
+    ctx.call("uwip_cvtColor_ex", C.byref(sb), C.byref(db), int(space), 1 if to_bgr else 0, 1 if opencv32 else 0)
     ctx.sync()
     return dst

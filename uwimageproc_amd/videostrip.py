@@ -44,12 +44,13 @@ class Features:
         except Exception:
             pass
 
-    def detect(self, frames: torch.Tensor, first_slot: int = 0, upright: bool = False, fixed_threshold: bool = False):
+    def detect(self, frames: torch.Tensor, first_slot: int = 0, upright: bool = False, relative_threshold: bool = False):
         """upright: SURF's `upright` parameter (no orientation estimate); the reference runs SURF oriented.
-        fixed_threshold: detector threshold 1e-3 instead of the contrast-relative one."""
+        relative_threshold: detector threshold relative to the frame's contrast (UWIP_OVERLAP_RELATIVE_THRESHOLD) instead of
+        the fixed 1e-3."""
         b = batch_of(frames)
         torch.cuda.current_stream(frames.device).synchronize()
-        self.ctx.call("uwip_overlap_detect_ex", C.byref(b), self._h, int(first_slot), (1 if upright else 0) | (2 if fixed_threshold else 0))
+        self.ctx.call("uwip_overlap_detect_ex", C.byref(b), self._h, int(first_slot), (1 if upright else 0) | (16 if relative_threshold else 0))
 
     def download(self, slot: int):
         kps = np.zeros(2048, KP_DTYPE)
@@ -59,11 +60,11 @@ class Features:
         return kps[:n.value].copy(), desc[:n.value].copy()
 
 
-OVERLAP_MIN4 = 4          # uwip.h UWIP_OVERLAP_MIN4: the reference's ">= 4 good matches" rule instead of >= 6 inliers
+OVERLAP_MIN6 = 8          # uwip.h UWIP_OVERLAP_MIN6: >= 6 RANSAC inliers instead of the reference's ">= 4 good matches" rule (the default)
 
 
 def match_pairs(ctx: Context, fq: Features, ft: Features, pair_q, pair_t, vw: int, vh: int, seed: int = 1,
-                want_matches: bool = False, min4: bool = False):
+                want_matches: bool = False, min6: bool = False):
     """kNN(2) + ratio test + homography + overlapArea for (object slot, key slot) pairs."""
     n = len(pair_q)
     dev = torch.device("cuda", ctx.device)
@@ -75,7 +76,7 @@ def match_pairs(ctx: Context, fq: Features, ft: Features, pair_q, pair_t, vw: in
     pq = (C.c_int32 * n)(*[int(v) for v in pair_q])
     pt = (C.c_int32 * n)(*[int(v) for v in pair_t])
     torch.cuda.synchronize()
-    ctx.call("uwip_overlap_match_ex", fq._h, ft._h, pq, pt, n, int(vw), int(vh), int(seed), OVERLAP_MIN4 if min4 else 0,
+    ctx.call("uwip_overlap_match_ex", fq._h, ft._h, pq, pt, n, int(vw), int(vh), int(seed), OVERLAP_MIN6 if min6 else 0,
              C.c_void_p(ratio.data_ptr()),
              C.c_void_p(info.data_ptr()), C.c_void_p(H.data_ptr()),
              C.c_void_p(midx.data_ptr()) if want_matches else None, C.c_void_p(mdist.data_ptr()) if want_matches else None)
