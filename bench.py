@@ -303,6 +303,13 @@ def spot_check_vs_oracle(orc, select, cap):
 
 
 I8_MFMA_PEAK_TOPS = 5000.0     # dense i8 = 2x the ~2.5 PFLOP/s dense BF16 rate (MI355X_MICROARCH.md, Matrix cores)
+FP4_MFMA_PEAK_TOPS = 10000.0   # dense FP4 / FP6 through v_mfma_scale_f32_*_f8f6f4 = 4x BF16 per clock (same guide)
+
+
+def matcher_form():
+    """(form id, operand name) the library's matcher runs (UWIP_MATCH_FORM; default 4 = FP4 E2M1 operands, 3 = round 4's i8)"""
+    f = int(os.environ.get("UWIP_MATCH_FORM", "4") or 4)
+    return f, ("fp4 (E2M1 nibbles, v_mfma_scale_f32_16x16x128_f8f6f4)" if f in (4, 5, 6) else "i8 (0/1 bytes, v_mfma_i32_16x16x64_i8)")
 # VALU issue: 1024 SIMDs.  The f32 rate in MI355X_MICROARCH.md (157 TFLOP/s vector f32 = 128 FMA lanes per CU and clock)
 # is one wave64 instruction per SIMD every 2 clocks = 1229 G wave-instr/s at 2.4 GHz; on this chip a dependent-free
 # stream of v_mul/v_add/v_fma_f32 issues one per 1.14 ns per SIMD (tools/ubench/valu_rate.hip) = 898 G/s, and the
@@ -399,8 +406,13 @@ def matcher_report(ctx, dev, pairs=64):
     avg = ms / cnt
     ops = 2.0 * K * K * 512 * pairs
     tops = ops / (avg * 1e-3) / 1e12
-    out = {"kernel": "k_ov_match", "workload": f"{pairs} pairs x ({K} x {K}) 512-bit descriptors (config 4)", "ops_per_launch": ops,
-           "avg_launch_ms": avg, "achieved": tops, "peak": I8_MFMA_PEAK_TOPS, "unit": "TOP/s", "frac": tops / I8_MFMA_PEAK_TOPS,
+    form, operands = matcher_form()
+    peak = FP4_MFMA_PEAK_TOPS if form in (4, 5, 6) else I8_MFMA_PEAK_TOPS
+    out = {"kernel": "k_ov_match", "form": form, "operands": operands,
+           "workload": f"{pairs} pairs x ({K} x {K}) 512-bit descriptors (config 4)", "ops_per_launch": ops,
+           "avg_launch_ms": avg, "achieved": tops, "peak": peak, "unit": "TOP/s", "frac": tops / peak,
+           "frac_of_i8_peak": tops / I8_MFMA_PEAK_TOPS, "frac_of_fp4_peak": tops / FP4_MFMA_PEAK_TOPS,
+           "peaks": {"i8_dense_TOPs": I8_MFMA_PEAK_TOPS, "fp4_dense_TOPs": FP4_MFMA_PEAK_TOPS},
            "bound": "mfma"}
     try:                                                     # MFMA counters of the committed rocprofv3 --pmc pass of tools/matcher_only.py
         mp = "r05_matcher_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_matcher_pmc.json")) else "r04_matcher_pmc.json"
@@ -607,9 +619,13 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
         mms, mcnt = res["k_ov_match"]
         ops = float(sum(2.0 * int(r[0]) * int(r[1]) * 512 for r in info)) * 1.0
         tops = ops / ((mms / mcnt) * 1e-3) / 1e12
-        roof["matcher"] = {"in_step": {"kernel": "k_ov_match", "pairs": int(len(info)), "mean_keypoints": float(np.mean(info[:, 0])),
-                                       "ops_per_launch": ops, "avg_launch_ms": mms / mcnt, "achieved": tops, "peak": I8_MFMA_PEAK_TOPS,
-                                       "unit": "TOP/s", "frac": tops / I8_MFMA_PEAK_TOPS, "bound": "mfma"}}
+        mform, mops = matcher_form()
+        mpeak = FP4_MFMA_PEAK_TOPS if mform in (4, 5, 6) else I8_MFMA_PEAK_TOPS
+        roof["matcher"] = {"in_step": {"kernel": "k_ov_match", "form": mform, "operands": mops, "pairs": int(len(info)),
+                                       "mean_keypoints": float(np.mean(info[:, 0])),
+                                       "ops_per_launch": ops, "avg_launch_ms": mms / mcnt, "achieved": tops, "peak": mpeak,
+                                       "unit": "TOP/s", "frac": tops / mpeak, "frac_of_i8_peak": tops / I8_MFMA_PEAK_TOPS,
+                                       "frac_of_fp4_peak": tops / FP4_MFMA_PEAK_TOPS, "bound": "mfma"}}
         if args.matcher_bench:
             try:
                 roof["matcher"]["config4_2048x2048"] = matcher_report(ctx, dev)

@@ -84,8 +84,12 @@ def _upload(ctx, f, slot, desc):
     ctx.call("uwip_features_upload", f._h, slot, 360, 640, C.c_void_p(kps.ctypes.data), C.c_void_p(desc.ctypes.data), n)
 
 
-def test_matcher_config4_2048x2048_exact(ctx, orc):
-    """The workload of roofline.matcher.config4_2048x2048: 64 pairs of full descriptor sets in ONE launch."""
+@pytest.mark.parametrize("form", ["4", "3"])
+def test_matcher_config4_2048x2048_exact(ctx, orc, form, monkeypatch):
+    """The workload of roofline.matcher.config4_2048x2048: 64 pairs of full descriptor sets in ONE launch -- with the FP4
+    operands of round 5 (UWIP_MATCH_FORM=4, the default: v_mfma_scale_f32_16x16x128_f8f6f4, E2M1 nibbles, float32 sums) and
+    with round 4's i8 operands (=3): the same (index, distance) pairs, exact."""
+    monkeypatch.setenv("UWIP_MATCH_FORM", form)          # re-read per call in a process started with UWIP_TEST_HOOKS=1
     rng = np.random.default_rng(7)
     pairs, K = 64, 2048
     f = vs.Features(ctx, 2 * pairs)
@@ -110,9 +114,11 @@ def test_matcher_config4_2048x2048_exact(ctx, orc):
     f.close()
 
 
+@pytest.mark.parametrize("form", ["4", "3", "5", "6"])
 @pytest.mark.parametrize("nq,nt", [(1, 1), (1, 2047), (63, 65), (65, 63), (255, 257), (257, 255), (2047, 1), (2047, 2048),
                                    (2048, 2047), (64, 64), (256, 2), (2, 256)])
-def test_matcher_ragged_counts_exact(ctx, orc, nq, nt):
+def test_matcher_ragged_counts_exact(ctx, orc, nq, nt, form, monkeypatch):
+    monkeypatch.setenv("UWIP_MATCH_FORM", form)          # 4 = FP4 (default), 3 = i8, 5 = FP4 128 columns per barrier, 6 = FP4 4-wave blocks
     rng = np.random.default_rng(nq * 4099 + nt)
     f = vs.Features(ctx, 2)
     # slots first filled to capacity, then refilled with the ragged counts: rows past the count hold stale descriptors

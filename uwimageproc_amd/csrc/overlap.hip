@@ -26,6 +26,7 @@ constexpr int NLEV = 4;
 constexpr int MAXKP = 2048;
 constexpr int DESC_BYTES = 64;     // packed bits
 constexpr int DESC_K = 512;        // unpacked 0/1 bytes for the i8 MFMA
+constexpr int DESC_NIBW = 64;      // the same 512 bits as FP4 E2M1 nibbles: 64 dwords = 256 bytes (the f8f6f4 MFMA operand)
 constexpr int BORDER = 8;
 constexpr float DTHRESH = 0.001f;
 constexpr int MIN_INLIERS = 4;       // default = the reference's rule: whatever findHomography returns for >= 4 good matches
@@ -62,12 +63,22 @@ struct uwip_features {
     int w = 0, h = 0;      // working (640-wide) size
     Keypoint *d_kp = nullptr;      // [capacity][MAXKP]
     uint8_t *d_desc = nullptr;     // [capacity][MAXKP][64]   packed
-    int8_t *d_bits = nullptr;      // [capacity][MAXKP][512]  0/1 bytes (MFMA operand)
+    int8_t *d_bits = nullptr;      // [capacity][MAXKP][512]  0/1 bytes (i8 MFMA operand)
+    uint32_t *d_nib = nullptr;     // [capacity][MAXKP][64]   0/1 as FP4 E2M1 nibbles, 0x0 / 0x2 = 0.0 / 1.0 (f8f6f4 MFMA operand)
     int32_t *d_pop = nullptr;      // [capacity][MAXKP]       popcounts
     int32_t *d_n = nullptr;        // [capacity]              keypoint counts
 };
 
 namespace {
+
+// 8 descriptor bits -> 8 FP4 E2M1 nibbles (bit j -> nibble j): 0 -> 0b0000 = 0.0, 1 -> 0b0010 = 1.0
+__device__ __forceinline__ uint32_t desc_byte_to_nibbles(uint32_t x)
+{
+    x = (x | (x << 12)) & 0x000F000Fu;
+    x = (x | (x << 6)) & 0x03030303u;
+    x = (x | (x << 3)) & 0x11111111u;
+    return x << 1;
+}
 
 // ---- resize (INTER_LINEAR, 8UC3, fixed point) + BGR2GRAY + /255 ---------------------------
 __global__ __launch_bounds__(256) void k_ov_resize_gray(const uint8_t *__restrict__ src, size_t step, size_t fs,
@@ -851,8 +862,8 @@ static __device__ const PairTab D_PAIRS = make_pair_tab();
 // over the 64 lanes.
 __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt, const float2 *__restrict__ Lxy,
                                                    int h, int w, Keypoint *__restrict__ kps, const int32_t *__restrict__ nkp,
-                                                   uint8_t *__restrict__ desc, int8_t *__restrict__ bits, int32_t *__restrict__ pop, int F,
-                                                   int upright)
+                                                   uint8_t *__restrict__ desc, int8_t *__restrict__ bits, uint32_t *__restrict__ nib,
+                                                   int32_t *__restrict__ pop, int F, int upright)
 {
     __shared__ __attribute__((aligned(16))) float2 s_v[112];     // (vx, vy) of the 109 disc samples; 109..111 stay zero
     __shared__ float s_val[29][3];
@@ -867,8 +878,10 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
     const int n = nkp[f];
     uint8_t *d = desc + ((size_t)f * MAXKP + q) * DESC_BYTES;
     int8_t *bq = bits + ((size_t)f * MAXKP + q) * DESC_K;
+    uint32_t *nq = nib + ((size_t)f * MAXKP + q) * DESC_NIBW;
     if (q >= n) {
         // unused slots: all-zero descriptor (keeps the MFMA operand defined)
+        nq[lane] = 0u;
         if (lane < 16) reinterpret_cast<uint32_t *>(d)[lane] = 0;
         for (int i = lane; i < DESC_K / 4; i += 64) reinterpret_cast<uint32_t *>(bq)[i] = 0;
         if (lane == 0) pop[(size_t)f * MAXKP + q] = 0;
@@ -963,6 +976,7 @@ __global__ __launch_bounds__(64) void k_ov_describe(const float *__restrict__ Lt
     for (int b = 486 + lane; b < DESC_K; b += 64) bq[b] = 0;
     __syncthreads();
     if (lane < 16) reinterpret_cast<uint32_t *>(d)[lane] = s_words[lane];
+    nq[lane] = desc_byte_to_nibbles((s_words[lane >> 2] >> (8 * (lane & 3))) & 255u);      // one coalesced 256-byte store
     if (lane == 0) {
         int pc = 0;
         for (int i = 0; i < 16; ++i) pc += __popc(s_words[i]);
@@ -1278,6 +1292,170 @@ __global__ __launch_bounds__(64 * NW) void k_ov_match_sp(const int8_t *__restric
                 out_idx[o] = h0 ? (int)(b0[u][r] & 2047u) : -1; out_idx[o + 1] = h1 ? (int)(b1[u][r] & 2047u) : -1;
                 out_dist[o] = h0 ? (int)(b0[u][r] >> 11) - 512 + cq[u][r] : -1;
                 out_dist[o + 1] = h1 ? (int)(b1[u][r] >> 11) - 512 + cq[u][r] : -1;
+            }
+        }
+}
+
+// ---- the same matcher on the FP4 form of the f8f6f4 MFMA (round 5) ---------------------------------------------------------
+// v_mfma_scale_f32_16x16x128_f8f6f4 with both operands E2M1: a descriptor bit travels as a NIBBLE (0x0 = 0.0, 0x2 = 1.0), 256
+// bytes per 512-bit descriptor instead of the 512 of the i8 form -- half the global and LDS bytes per MAC -- and one
+// instruction covers K = 128: four MFMAs per 16 x 16 x 512 tile instead of eight, at the cycles of the i8 instruction (twice
+// its MAC rate; MI355X_MICROARCH.md, Matrix cores).  Block scales are E8M0 bytes of 127 = 2^0.  The products are 0 or 1 and a
+// sum is at most 512: exact in the float32 accumulator.  The packed key (distance, train index) is formed and compared as
+// FLOAT -- (|t| + 512 - 2 a.b) * 2048 + t < 2^22 is exact in float32, one v_fma_f32 from the accumulator, v_min / v_max_f32
+// for the top-2 insertion: the same four vector instructions per result as the integer form -- and converted once at the end.
+// Both operands' lanes read their 32 nibbles of a K = 128 step from the same byte offsets of a descriptor, so whatever k
+// order the hardware assigns inside a lane, the two sides agree: the sum is the dot product.
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int F4_DESC = DESC_NIBW * 4;                 // 256 bytes per descriptor
+constexpr int F4_ROW = F4_DESC + 32;                   // LDS row stride (the i8 form's argument: 2 row + kb mod 16 slots)
+constexpr float F4_DEAD = 8388608.0f;                  // any key >= 2^23 is dead (live keys are < 2^22)
+constexpr float F4_EMPTY = 3.0e9f;
+__device__ __forceinline__ void top2_push_f(float &b0, float &b1, float k)
+{
+    b1 = fminf(b1, fmaxf(b0, k));
+    b0 = fminf(b0, k);
+}
+__device__ __forceinline__ v4f mfma_f4(const v4i &a, const v4i &b, const v4f &c)
+{
+    const v8i A = {a[0], a[1], a[2], a[3], 0, 0, 0, 0}, B = {b[0], b[1], b[2], b[3], 0, 0, 0, 0};
+    // cbsz = blgp = 4: FP4 E2M1 on both sides; scale operands: four E8M0 bytes of 127 (x 1.0), byte 0 selected
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, B, c, 4, 4, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+template <int QT, int NW, int TG>
+__global__ __launch_bounds__(64 * NW) void k_ov_match_f4(const uint32_t *__restrict__ qnib, const int32_t *__restrict__ qpop,
+                                                    const int32_t *__restrict__ qn, const uint32_t *__restrict__ tnib,
+                                                    const int32_t *__restrict__ tpop, const int32_t *__restrict__ tn,
+                                                    const int32_t *__restrict__ pair_q, const int32_t *__restrict__ pair_t,
+                                                    int32_t *__restrict__ out_idx /*[P][MAXKP][2]*/, int32_t *__restrict__ out_dist)
+{
+    extern __shared__ __attribute__((aligned(16))) int8_t s_t[];      // 2 x [TC][F4_ROW] descriptors, then 2 x [TC] keys
+    const int p = blockIdx.y;
+    const int fq = pair_q[p], ft = pair_t[p];
+    const int nq = qn[fq], nt = tn[ft];
+    const int q0 = blockIdx.x * (16 * NW * QT);
+    if (q0 >= nq) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = lane & 15, kb = lane >> 4;
+    const int8_t *Q = reinterpret_cast<const int8_t *>(qnib) + (size_t)fq * MAXKP * F4_DESC;
+    const int8_t *T = reinterpret_cast<const int8_t *>(tnib) + (size_t)ft * MAXKP * F4_DESC;
+    const int32_t *TP = tpop + (size_t)ft * MAXKP;
+    v4i a[QT][4];
+    int cq[QT][4];
+    float b0[QT][4], b1[QT][4];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) {
+        const int qrow = q0 + (wave * QT + u) * 16 + row;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            a[u][ks] = *reinterpret_cast<const v4i *>(Q + (size_t)qrow * F4_DESC + ks * 64 + kb * 16);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            cq[u][r] = qpop[(size_t)fq * MAXKP + q0 + (wave * QT + u) * 16 + kb * 4 + r];
+            b0[u][r] = b1[u][r] = F4_EMPTY;
+        }
+    }
+    constexpr int TC = TG * 16;               // train columns per tile
+    constexpr int NP = TC * 16 / (64 * NW);   // 16-byte pieces per thread
+    constexpr int NK = (TC + 63) / 64;        // keys per lane
+    static_assert(TG % 2 == 0 && TC * 16 % (64 * NW) == 0 && NP >= 1, "tile shape");
+    v4i stage[NP];
+    float stage_key[NK];
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = threadIdx.x + 64 * NW * j, tr = i >> 4, piece = i & 15;
+            stage[j] = *reinterpret_cast<const v4i *>(T + (size_t)(t0 + tr) * F4_DESC + piece * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            const int t = t0 + lane + 64 * j;
+            const int pc = TP[min(t, MAXKP - 1)];
+            // live: (|t| + 512) * 2048 + t, exact in float32; a dead column adds 2^23 (no select on a loaded value: see the i8 form)
+            stage_key[j] = (float)(((pc + 512) << 11) | t) + (t < nt ? 0.0f : F4_DEAD);
+        }
+    };
+    int8_t *const bufA = s_t, *const bufB = s_t + (size_t)TC * F4_ROW;
+    float *const keyA = reinterpret_cast<float *>(s_t + (size_t)2 * TC * F4_ROW), *const keyB = keyA + TC;
+    auto park = [&](int8_t *buf, float *kbuf) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int i = threadIdx.x + 64 * NW * j, tr = i >> 4, piece = i & 15;
+            *reinterpret_cast<v4i *>(buf + (size_t)tr * F4_ROW + piece * 16) = stage[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NK; ++j) if (lane + 64 * j < TC) kbuf[lane + 64 * j] = stage_key[j];
+    };
+    if (nt > 0) {
+        fetch(0);
+        park(bufA, keyA);
+        fetch(TC);
+    }
+    __syncthreads();
+    v4f acc[2][QT];
+#pragma unroll
+    for (int u = 0; u < QT; ++u) acc[1][u] = v4f{0.f, 0.f, 0.f, 0.f};
+    float tb_last = F4_DEAD;
+    auto epilogue_one = [&](const v4f (&ac)[QT], float tbk, int idx) {
+        const int u = idx >> 2, r = idx & 3;
+        const float mf = tbk >= F4_DEAD ? 0.0f : -4096.0f;
+        top2_push_f(b0[u][r], b1[u][r], fmaf(ac[u][r], mf, tbk));
+    };
+    for (int t0 = 0, it = 0; t0 < nt; t0 += TC, ++it) {
+        const int8_t *cur = (it & 1) ? bufB : bufA;
+        const float *kcur = (it & 1) ? keyB : keyA;
+        float tb[TG];
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) tb[tt] = kcur[tt * 16 + row];
+        v4i bf[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            bf[0][ks] = *reinterpret_cast<const v4i *>(cur + (size_t)row * F4_ROW + ks * 64 + kb * 16);
+#pragma unroll
+        for (int tt = 0; tt < TG; ++tt) {
+            if (tt < TG - 1) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    bf[(tt + 1) & 1][ks] = *reinterpret_cast<const v4i *>(cur + (size_t)((tt + 1) * 16 + row) * F4_ROW + ks * 64 + kb * 16);
+            }
+            const float tbk = tt == 0 ? tb_last : tb[(tt + TG - 1) % TG];
+#pragma unroll
+            for (int u = 0; u < QT; ++u) acc[tt & 1][u] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int u = 0; u < QT; ++u) acc[tt & 1][u] = mfma_f4(a[u][ks], bf[tt & 1][ks], acc[tt & 1][u]);
+                // the QT * 4 pending results of the previous group over the 4 steps of this one
+#pragma unroll
+                for (int e = 0; e < QT; ++e) epilogue_one(acc[(tt + 1) & 1], tbk, ks * QT + e);
+            }
+        }
+        tb_last = tb[TG - 1];
+        park((it & 1) ? bufA : bufB, (it & 1) ? keyA : keyB);
+        fetch(min(t0 + 2 * TC, MAXKP - TC));
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < QT * 4; ++i) epilogue_one(acc[1], tb_last, i);
+#pragma unroll
+    for (int u = 0; u < QT; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                const float o0 = __shfl_xor(b0[u][r], d, 64), o1 = __shfl_xor(b1[u][r], d, 64);
+                top2_push_f(b0[u][r], b1[u][r], o0);
+                top2_push_f(b0[u][r], b1[u][r], o1);
+            }
+            const int q = q0 + (wave * QT + u) * 16 + kb * 4 + r;
+            if (row == 0 && q < nq) {
+                const size_t o = ((size_t)p * MAXKP + q) * 2;
+                const bool h0 = b0[u][r] < F4_DEAD, h1 = b1[u][r] < F4_DEAD;
+                const int k0 = h0 ? (int)b0[u][r] : 0, k1 = h1 ? (int)b1[u][r] : 0;
+                out_idx[o] = h0 ? (k0 & 2047) : -1; out_idx[o + 1] = h1 ? (k1 & 2047) : -1;
+                out_dist[o] = h0 ? (k0 >> 11) - 512 + cq[u][r] : -1;
+                out_dist[o + 1] = h1 ? (k1 >> 11) - 512 + cq[u][r] : -1;
             }
         }
 }
@@ -1961,6 +2139,7 @@ int detect_describe(uwip_ctx *ctx, OvWork &W, int F, int h, int w, uwip_features
         k_ov_describe<<<8u * (((unsigned)MAXKP * F + 7u) / 8u), 64, 0, ctx->stream>>>(W.Lt, W.Lxy, h, w, kps, nkp,
                                                              ft->d_desc + (size_t)first_slot * MAXKP * DESC_BYTES,
                                                              ft->d_bits + (size_t)first_slot * MAXKP * DESC_K,
+                                                             ft->d_nib + (size_t)first_slot * MAXKP * DESC_NIBW,
                                                              ft->d_pop + (size_t)first_slot * MAXKP, F, upright);
         UWIP_HIP(ctx, hipGetLastError());
     }
@@ -1981,9 +2160,10 @@ UWIP_API int uwip_features_create(uwip_ctx *ctx, int max_frames, uwip_features *
     f->ctx = ctx; f->capacity = max_frames;
     const size_t K = (size_t)max_frames * MAXKP;
     if (hipMalloc(&f->d_kp, K * sizeof(Keypoint)) != hipSuccess || hipMalloc(&f->d_desc, K * DESC_BYTES) != hipSuccess ||
-        hipMalloc(&f->d_bits, K * DESC_K) != hipSuccess || hipMalloc(&f->d_pop, K * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc(&f->d_bits, K * DESC_K) != hipSuccess || hipMalloc(&f->d_nib, K * DESC_NIBW * 4) != hipSuccess ||
+        hipMalloc(&f->d_pop, K * sizeof(int32_t)) != hipSuccess ||
         hipMalloc(&f->d_n, sizeof(int32_t) * max_frames) != hipSuccess) {
-        (void)hipFree(f->d_kp); (void)hipFree(f->d_desc); (void)hipFree(f->d_bits); (void)hipFree(f->d_pop); (void)hipFree(f->d_n);
+        (void)hipFree(f->d_kp); (void)hipFree(f->d_desc); (void)hipFree(f->d_bits); (void)hipFree(f->d_nib); (void)hipFree(f->d_pop); (void)hipFree(f->d_n);
         delete f;
         return ctx->fail(UWIP_ERR_NOMEM, "feature set hipMalloc");
     }
@@ -1993,6 +2173,7 @@ UWIP_API int uwip_features_create(uwip_ctx *ctx, int max_frames, uwip_features *
     uwip_trace_range(ctx, "device", "features.pop", f->d_pop, K * sizeof(int32_t));
     (void)hipMemsetAsync(f->d_n, 0, sizeof(int32_t) * max_frames, ctx->stream);
     (void)hipMemsetAsync(f->d_bits, 0, K * DESC_K, ctx->stream);
+    (void)hipMemsetAsync(f->d_nib, 0, K * DESC_NIBW * 4, ctx->stream);
     (void)hipMemsetAsync(f->d_pop, 0, K * sizeof(int32_t), ctx->stream);
     *out = f;
     return UWIP_OK;
@@ -2003,7 +2184,7 @@ UWIP_API int uwip_features_destroy(uwip_features *f)
     if (!f) return UWIP_OK;
     (void)hipSetDevice(f->ctx->device);
     (void)uwip_stream_wait(f->ctx);
-    (void)hipFree(f->d_kp); (void)hipFree(f->d_desc); (void)hipFree(f->d_bits); (void)hipFree(f->d_pop); (void)hipFree(f->d_n);
+    (void)hipFree(f->d_kp); (void)hipFree(f->d_desc); (void)hipFree(f->d_bits); (void)hipFree(f->d_nib); (void)hipFree(f->d_pop); (void)hipFree(f->d_n);
     delete f;
     return UWIP_OK;
 }
@@ -2085,7 +2266,7 @@ UWIP_API int uwip_features_download(uwip_ctx *ctx, const uwip_features *feats, i
 // matcher is measured on a full 2048 x 2048 descriptor set.  Rows >= count are zeroed.
 namespace {
 __global__ __launch_bounds__(256) void k_ov_unpack_desc(const uint8_t *__restrict__ desc, int count, int8_t *__restrict__ bits,
-                                                       int32_t *__restrict__ pop)
+                                                       uint32_t *__restrict__ nib, int32_t *__restrict__ pop)
 {
     const int k = blockIdx.x;                         // keypoint
     const int t = threadIdx.x;                        // 2 bits per thread -> 512
@@ -2094,6 +2275,7 @@ __global__ __launch_bounds__(256) void k_ov_unpack_desc(const uint8_t *__restric
     const int b0 = live ? (d[(2 * t) >> 3] >> ((2 * t) & 7)) & 1 : 0, b1 = live ? (d[(2 * t + 1) >> 3] >> ((2 * t + 1) & 7)) & 1 : 0;
     bits[(size_t)k * DESC_K + 2 * t] = (int8_t)b0;
     bits[(size_t)k * DESC_K + 2 * t + 1] = (int8_t)b1;
+    if (t < DESC_NIBW) nib[(size_t)k * DESC_NIBW + t] = live ? desc_byte_to_nibbles(d[t]) : 0u;
     __shared__ int s_c[4];
     int c = b0 + b1;
 #pragma unroll
@@ -2125,7 +2307,7 @@ UWIP_API int uwip_features_upload(uwip_ctx *ctx, uwip_features *feats, int slot,
     }
     UWIP_HIP(ctx, hipMemcpy(feats->d_n + slot, &count, sizeof(int32_t), hipMemcpyHostToDevice));
     k_ov_unpack_desc<<<MAXKP, 256, 0, ctx->stream>>>(stage, count, feats->d_bits + (size_t)slot * MAXKP * DESC_K,
-                                                     feats->d_pop + (size_t)slot * MAXKP);
+                                                     feats->d_nib + (size_t)slot * MAXKP * DESC_NIBW, feats->d_pop + (size_t)slot * MAXKP);
     UWIP_HIP(ctx, hipGetLastError());
     UWIP_HIP(ctx, uwip_stream_wait(ctx));
     return UWIP_OK;
@@ -2211,7 +2393,10 @@ UWIP_API int uwip_overlap_match_ex(uwip_ctx *ctx, const uwip_features *fq, const
     {
         uwip_kscope ks(ctx, "k_ov_match");
         constexpr int QT = 2;            // 2 query tiles of 16 per wave
-        static const int form = [] { const char *e = std::getenv("UWIP_MATCH_FORM"); return e && *e ? std::atoi(e) : 1; }();
+        // UWIP_MATCH_FORM: 4 (default) FP4 operands; 3 the i8 form of round 4; 0 / 2 / 5 / 6 older and experimental shapes
+        auto read_form = [] { const char *e = std::getenv("UWIP_MATCH_FORM"); return e && *e ? std::atoi(e) : 4; };
+        static const int form_once = read_form();
+        const int form = uwip_test_hooks() ? read_form() : form_once;      // tests switch forms inside one process
 #define UWIP_LAUNCH_MATCH(KERNEL, NWV, LDSB)                                                                                   \
         do {                                                                                                                   \
             int rc_l = uwip_lds_optin(ctx, #KERNEL, (const void *)KERNEL, (LDSB));                                             \
@@ -2220,11 +2405,23 @@ UWIP_API int uwip_overlap_match_ex(uwip_ctx *ctx, const uwip_features *fq, const
                                                                                          ft->d_pop, ft->d_n, d_pairs, d_pairs + npairs, m_idx, m_dist); \
         } while (0)
         const size_t lds0 = (size_t)2 * 64 * MT_ROW, lds1 = lds0 + 2 * 64 * sizeof(uint32_t), lds2 = 2 * lds1;
+#define UWIP_LAUNCH_MATCH_F4(KERNEL, NWV, LDSB)                                                                                \
+        do {                                                                                                                   \
+            int rc_l = uwip_lds_optin(ctx, #KERNEL, (const void *)KERNEL, (LDSB));                                             \
+            if (rc_l) return rc_l;                                                                                             \
+            KERNEL<<<dim3(MAXKP / (16 * (NWV) * QT), npairs), 64 * (NWV), (LDSB), ctx->stream>>>(fq->d_nib, fq->d_pop, fq->d_n, ft->d_nib, \
+                                                                                         ft->d_pop, ft->d_n, d_pairs, d_pairs + npairs, m_idx, m_dist); \
+        } while (0)
+        const size_t ldsf4 = (size_t)2 * 64 * F4_ROW + 2 * 64 * sizeof(float), ldsf8 = (size_t)2 * 128 * F4_ROW + 2 * 128 * sizeof(float);
         switch (form) {                  // variants kept for A/B (tools/matcher_only.py): 0 = the round 2-3 kernel
         case 0: UWIP_LAUNCH_MATCH((k_ov_match<QT, 8>), 8, lds0); break;
         case 2: UWIP_LAUNCH_MATCH((k_ov_match_sp<QT, 8, 8>), 8, lds2); break;       // 128 train columns per barrier
-        default: UWIP_LAUNCH_MATCH((k_ov_match_sp<QT, 8, 4>), 8, lds1); break;
+        case 3: UWIP_LAUNCH_MATCH((k_ov_match_sp<QT, 8, 4>), 8, lds1); break;       // round 4's i8 form
+        case 5: UWIP_LAUNCH_MATCH_F4((k_ov_match_f4<QT, 8, 8>), 8, ldsf8); break;   // FP4, 128 train columns per barrier
+        case 6: UWIP_LAUNCH_MATCH_F4((k_ov_match_f4<QT, 4, 4>), 4, ldsf4); break;   // FP4, 4-wave blocks
+        default: UWIP_LAUNCH_MATCH_F4((k_ov_match_f4<QT, 8, 4>), 8, ldsf4); break;  // FP4 operands (round 5)
         }
+#undef UWIP_LAUNCH_MATCH_F4
 #undef UWIP_LAUNCH_MATCH
         UWIP_HIP(ctx, hipGetLastError());
     }
@@ -2321,6 +2518,7 @@ UWIP_API int uwip_features_copy(uwip_ctx *ctx, const uwip_features *src, int src
     UWIP_HIP(ctx, hipMemcpyAsync(dst->d_kp + d, src->d_kp + s, sizeof(Keypoint) * MAXKP, hipMemcpyDeviceToDevice, ctx->stream));
     UWIP_HIP(ctx, hipMemcpyAsync(dst->d_desc + d * DESC_BYTES, src->d_desc + s * DESC_BYTES, (size_t)MAXKP * DESC_BYTES, hipMemcpyDeviceToDevice, ctx->stream));
     UWIP_HIP(ctx, hipMemcpyAsync(dst->d_bits + d * DESC_K, src->d_bits + s * DESC_K, (size_t)MAXKP * DESC_K, hipMemcpyDeviceToDevice, ctx->stream));
+    UWIP_HIP(ctx, hipMemcpyAsync(dst->d_nib + d * DESC_NIBW, src->d_nib + s * DESC_NIBW, (size_t)MAXKP * DESC_NIBW * 4, hipMemcpyDeviceToDevice, ctx->stream));
     UWIP_HIP(ctx, hipMemcpyAsync(dst->d_pop + d, src->d_pop + s, sizeof(int32_t) * MAXKP, hipMemcpyDeviceToDevice, ctx->stream));
     UWIP_HIP(ctx, hipMemcpyAsync(dst->d_n + dst_slot, src->d_n + src_slot, sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
     return UWIP_OK;
