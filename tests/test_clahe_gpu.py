@@ -473,9 +473,18 @@ def test_aclahe_async_equals_synchronous_forms(ctx, orc, shape, monkeypatch):
     # (the hook acts in the device choice; the synchronous forms re-select on the host for such frames, so the check here is
     # against the oracle: BS = last arg-max of the float16 entropies of CLAHE(blurred plane, 30, g), output = CLAHE(plane, 30, BS))
     monkeypatch.setenv("UWIP_ACLAHE_TEST_FORCE_CL", "30")
+    ctx.prof_reset(); ctx.prof_enable(True)
     q_async, r_async = _auto(ctx, t, 1 | 4)
+    prof = ctx.prof_results()
+    ctx.prof_enable(False)
     monkeypatch.delenv("UWIP_ACLAHE_TEST_FORCE_CL")
     assert all(c == 30 for _, c in q_async), q_async
+    # k_aclahe_exact_bs is ONE block per flagged frame walking the plane five times -- the worst case of the "no host
+    # wait" stage, reached only by a degenerate fit (none in 1043 tables).  Its cost with EVERY frame flagged
+    # is bounded here (the blocks of different frames run side by side): < 8 ms at 270 x 480, < 120 ms at 1080p.
+    ms, cnt = prof["k_aclahe_exact_bs"]
+    print(f"k_aclahe_exact_bs, all {F} frames of {cols}x{rows} flagged: {ms / cnt:.2f} ms")
+    assert ms / cnt < (8.0 if rows < 1000 else 120.0), ms / cnt
     for f in range(F if rows < 1000 else 2):
         filt = orc.gaussian3(frames[f])
         ent = np.array([orc.entropy(orc.clahe(filt, 30.0, g, g)) for g in (2, 4, 8, 16, 32)], np.float32).astype(np.float16)
