@@ -30,4 +30,8 @@ for set in "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES 
   timeout -k 10 240 rocprofv3 --pmc $set -d gpurun_out/pmcm_${tag}_$j --output-format csv -- python3 tools/matcher_only.py > gpurun_out/pmcm_${tag}_$j.log 2>&1 || true
 done
 timeout -k 10 120 python3 tools/matcher_only.py > gpurun_out/matcher_${tag}.json 2> /dev/null || true
+UWIP_MATCH_FORM=3 timeout -k 10 120 python3 tools/matcher_only.py > gpurun_out/matcher_i8_${tag}.json 2> /dev/null || true
+# 5. pairwise co-residency of the pipe's kernels (two streams), and the per-kernel time table of one sub-batch
+echo "co-run matrix"; timeout -k 10 300 python3 tools/corun_matrix.py --json gpurun_out/corun_${tag}.json > gpurun_out/corun_${tag}.txt 2>&1 || true
+timeout -k 10 120 python3 tools/kernel_times.py 64 3 > gpurun_out/kernel_times_${tag}.txt 2>&1 || true
 echo done

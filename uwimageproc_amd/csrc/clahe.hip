@@ -1233,28 +1233,35 @@ int launch_apply_mixed(uwip_ctx *ctx, const uwip_batch_u8 *src, const uwip_batch
 // ---- the block-size search at a clip limit OUTSIDE the swept grid, on the device (ACLAHE.py:102-112) -----------------------
 // A knee index d >= 26 makes d itself (the reference uses the index as a clip limit) leave the sweep's 0 .. 25: the five
 // entropies at that clip limit are then evaluated for the frame.  It takes a degenerate fit to get here, so
-// this is written for correctness, not speed: ONE block per flagged frame walks the five grids -- tile histograms by global
-// atomics into the frame's slice of the tile-histogram workspace, LUT rows by clahe_lut_rows, the CLAHE output of every pixel
+// this is written for correctness, not speed: one block per (flagged frame, grid) -- tile histograms by global atomics into
+// the (frame, grid) slice of the tile-histogram workspace, LUT rows by clahe_lut_rows, the CLAHE output of every pixel
 // (cv::CLAHE's float32 blend, the operations of k_clahe_apply) counted into a 256-bin LDS histogram without being stored,
-// aclaheEntropy (k_entropy's operations) -- and rewrites the frame's BS.  Blocks of unflagged frames exit at once.
+// aclaheEntropy (k_entropy's operations); the last of a frame's five blocks to finish (an arrival counter in the spare field
+// of the frame's parameter record) rewrites the frame's BS.  Blocks of unflagged frames exit at once.  Worst case (every
+// frame of a batch flagged: tests/test_clahe_gpu.py measures it) ~13 ms at 1080p -- round 4 walked the five grids in ONE
+// block per frame: 63 ms.
+// tiles of the grids 2, 4, 8, 16, 32 one after the other: offsets 0, 4, 20, 84, 340 = (4^(k+1) - 4) / 3, 1364 per frame
+constexpr int EXACT_TILES = 1364;
+__device__ __forceinline__ int exact_tile_off(int k) { return ((4 << (2 * k)) - 4) / 3; }
 struct ExactGrids {
     int g[5], tw[5], th[5], pc[5], pr[5], area[5];
     float inv_tw[5], inv_th[5], lutScale[5];
 };
 __global__ __launch_bounds__(512) void k_aclahe_exact_bs(const uint8_t *__restrict__ src, size_t step, size_t fstride, int rows, int cols,
                                                         ExactGrids G, int rule, int32_t *__restrict__ par /*[F][4]*/,
-                                                        uint32_t *__restrict__ hist_ws /*[F][1024][256]*/, uint8_t *__restrict__ lut_ws /*[F][1024][256]*/)
+                                                        uint32_t *__restrict__ hist_ws /*[F][1364][256]*/, uint8_t *__restrict__ lut_ws /*[F][1364][256]*/,
+                                                        float *__restrict__ ent_ws /*[F][5]*/)
 {
     const int f = blockIdx.x;
-    if (par[4 * f + 2] != 1) return;
+    if (par[4 * f + 2] != 1) return;             // (the last block of a flagged frame writes 2 only after all five have read this)
     __shared__ uint32_t s_out[256];
-    __shared__ float s_ent[5];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = par[4 * f + 1];
     const uint8_t *plane = src + (size_t)f * fstride;
-    uint32_t *hist = hist_ws + (size_t)f * 1024 * 256;
-    uint8_t *lut = lut_ws + (size_t)f * 1024 * 256;
-    for (int k = 0; k < 5; ++k) {
+    {
+        const int k = blockIdx.y;
+        uint32_t *hist = hist_ws + ((size_t)f * EXACT_TILES + exact_tile_off(k)) * 256;
+        uint8_t *lut = lut_ws + ((size_t)f * EXACT_TILES + exact_tile_off(k)) * 256;
         const int gx = G.g[k], gy = G.g[k], tiles = gx * gy, tw = G.tw[k], th = G.th[k], pc = G.pc[k], pr = G.pr[k];
         for (int i = tid; i < tiles * 256; i += 512) hist[i] = 0;
         if (tid < 256) s_out[tid] = 0;
@@ -1298,19 +1305,21 @@ __global__ __launch_bounds__(512) void k_aclahe_exact_bs(const uint8_t *__restri
                 const float p = (float)s_out[i] / (float)(cols * rows);
                 e = (float)((double)e + (double)p * log2((double)p + 0.00001));
             }
-            s_ent[k] = -e;
+            ent_ws[(size_t)f * 5 + k] = -e;
+            __threadfence();
+            if (atomicAdd(&par[4 * f + 3], 1) == 4) {              // the last of the frame's five blocks
+                __threadfence();
+                int w = 0;
+                float best = 0.f;
+                for (int q = 0; q < 5; ++q) {
+                    const float h = (float)(_Float16)__hip_atomic_load(&ent_ws[(size_t)f * 5 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (q == 0 || h >= best) { best = h; w = q; }  // last maximum wins (ACLAHE.py:118-124)
+                }
+                par[4 * f + 0] = G.g[w];
+                par[4 * f + 3] = 0;
+                par[4 * f + 2] = 2;                                  // evaluated
+            }
         }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        int w = 0;
-        float best = 0.f;
-        for (int k = 0; k < 5; ++k) {
-            const float h = (float)(_Float16)s_ent[k];
-            if (k == 0 || h >= best) { best = h; w = k; }          // last maximum wins (ACLAHE.py:118-124)
-        }
-        par[4 * f + 0] = G.g[w];
-        par[4 * f + 2] = 2;                                          // evaluated
     }
 }
 
@@ -1541,12 +1550,13 @@ static int aclahe_exact_bs_device(uwip_ctx *ctx, const uwip_batch_u8 *src, int32
         G.g[k] = BlockSize[k]; G.tw[k] = g.tw; G.th[k] = g.th; G.pc[k] = g.pc; G.pr[k] = g.pr; G.area[k] = g.area;
         G.inv_tw[k] = g.inv_tw; G.inv_th[k] = g.inv_th; G.lutScale[k] = g.lutScale;
     }
-    uint32_t *d_hists = (uint32_t *)uwip_ws(ctx, "clahe.tilehist", sizeof(uint32_t) * 256 * (size_t)1024 * F);
-    uint8_t *d_luts = (uint8_t *)uwip_ws(ctx, "sweep.luts", (size_t)256 * 1024 * SWEEP_NCL * F);
-    if (!d_hists || !d_luts) return UWIP_ERR_NOMEM;
+    uint32_t *d_hists = (uint32_t *)uwip_ws(ctx, "clahe.tilehist", sizeof(uint32_t) * 256 * (size_t)EXACT_TILES * F);
+    uint8_t *d_luts = (uint8_t *)uwip_ws(ctx, "sweep.luts", (size_t)256 * 1024 * SWEEP_NCL * F);      // >= 256 * EXACT_TILES * F
+    float *d_ent = (float *)uwip_ws(ctx, "auto.exact_ent", sizeof(float) * 5 * (size_t)F);
+    if (!d_hists || !d_luts || !d_ent) return UWIP_ERR_NOMEM;
     uwip_kscope ks(ctx, "k_aclahe_exact_bs");
-    k_aclahe_exact_bs<<<F, 512, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, src->rows, src->cols, G,
-                                                  residual_rule, d_par, d_hists, d_luts);
+    k_aclahe_exact_bs<<<dim3(F, 5), 512, 0, ctx->stream>>>((const uint8_t *)src->data, src->step, src->frame_stride, src->rows, src->cols, G,
+                                                           residual_rule, d_par, d_hists, d_luts, d_ent);
     UWIP_HIP(ctx, hipGetLastError());
     return UWIP_OK;
 }
