@@ -1312,9 +1312,11 @@ constexpr int F4_DESC = DESC_NIBW * 4;                 // 256 bytes per descript
 constexpr int F4_ROW = F4_DESC + 32;                   // LDS row stride (the i8 form's argument: 2 row + kb mod 16 slots)
 constexpr float F4_DEAD = 8388608.0f;                  // any key >= 2^23 is dead (live keys are < 2^22)
 constexpr float F4_EMPTY = 3.0e9f;
+// b0 <= b1 always, so the new second-best min(b1, max(b0, k)) is the MEDIAN of (b0, b1, k): one v_med3_f32 instead of a
+// max and a min -- three vector instructions per result (fma, med3, min) where the integer form has four
 __device__ __forceinline__ void top2_push_f(float &b0, float &b1, float k)
 {
-    b1 = fminf(b1, fmaxf(b0, k));
+    b1 = __builtin_amdgcn_fmed3f(b0, b1, k);
     b0 = fminf(b0, k);
 }
 __device__ __forceinline__ v4f mfma_f4(const v4i &a, const v4i &b, const v4f &c)
