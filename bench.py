@@ -536,17 +536,18 @@ def roofline_report(args, pipe, part0, dev, F, Fs, H, W):
         lds = {"idx_active_cycles_per_cu_per_launch": cyc_cu, "busy_frac": cyc_cu / ((dms / dcnt) * 1e-3 * 2.4e9),
                "bank_conflict_frac_of_active": e.get("lds_bank_conflict_per_frame", 0.0) / e["lds_idx_active_per_frame"],
                "source": "SQ_LDS_IDX_ACTIVE / SQ_LDS_BANK_CONFLICT of the committed --pmc pass, time from this run"}
+    # the contract's form: the dominant kernel against the HBM roofline with SURVEY 8(d)'s algorithmic bytes (achieved, peak,
+    # frac, traffic).  For the sweep that reading is ~1 % -- it evaluates ~125 CLAHE outputs per pixel from one read of the
+    # plane, VALU issue and the LDS pipe bind it -- so the limits that DO bind it ride along as `valu` / `lds` /
+    # `binding_limit`, next to the HBM figures, not instead of them (rounds 2-4 had the VALU reading on top: VERDICT r4).
+    roof = dict(hb)
+    roof["hbm_frac"] = hb.get("frac")
+    roof["valu"], roof["lds"] = valu, lds
     if dom_name.startswith("k_clahe_sweep") and valu is not None:
-        # the sweep is bound by VALU issue (and the LDS pipe), not by HBM: price it there, keep the HBM reading beside it
-        roof = {"bound": "valu", "kernel": dom_name, "achieved": valu["achieved_Ginstr_per_s"], "peak": VALU_PEAK_GINSTR,
-                "unit": "G wave-instr/s", "frac": valu["frac"], "traffic": hb.get("traffic"),
-                "traffic_over_algorithmic": hb.get("traffic_over_algorithmic"), "avg_launch_ms": dms / dcnt,
-                "hbm": hb, "hbm_frac": hb.get("frac"), "valu": valu, "lds": lds,
-                "bound_note": "the histogram sweep evaluates up to 255 CLAHE outputs per pixel from one read of the plane: VALU issue "
-                              "and the LDS pipe bind it; `hbm` prices the same launch against SURVEY 8(d)'s N bytes per frame"}
-    else:
-        roof = dict(hb)
-        roof["valu"], roof["lds"] = valu, lds
+        roof["binding_limit"] = {"what": "VALU issue + LDS pipe", "valu_frac_of_measured_issue_rate": valu["frac"],
+                                 "valu_frac_of_spec_rate": valu["frac_of_spec"], "lds_busy_frac": None if lds is None else lds["busy_frac"],
+                                 "note": "DESIGN.md section 5: 16.5 VALU + 1.5 LDS instructions per evaluation, 24 ns per wave-evaluation per SIMD -> "
+                                         "a 7.4 ms floor for this exact-f32 formulation on the bench's frames"}
     roof["ms_per_subbatch"] = kernels[dom_name]["ms_per_subbatch"]
     roof["share_of_step"] = kernels[dom_name]["ms_per_subbatch"] / tot
     roof["is"] = "the kernel with the largest share of the step's kernel time"

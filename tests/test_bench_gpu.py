@@ -41,6 +41,16 @@ def test_bench_self_launches_two_ranks():
     assert one["outputs_identical_across_streams"] is True and two["outputs_identical_across_streams"] is True
     assert two["spot_check_vs_oracle"] is not None and two["spot_check_vs_oracle"]["ok"], two["spot_check_vs_oracle"]
     assert one["host_cpu_s_per_step"] > 0
+    # round 5: the timed region on three scenes (every rank takes part), the rules the step ran under, the matcher against both peaks
+    for d in (one, two):
+        sc = d["scenes"]
+        assert len(sc["per_scene"]) == 3 and len({s["seed0"] for s in sc["per_scene"]}) == 3
+        lo, med, hi = sc["frames_per_s_min_median_max"]
+        assert 0 < lo <= med <= hi and sc["per_scene"][0]["frames_per_s"] == d["value"]
+        assert "GUARD_S" in d["config"]["rules"]["dehaze_S"] and ">= 4 good matches" in d["config"]["rules"]["overlap"]
+    m = one["roofline"]["matcher"]["in_step"]
+    assert m["form"] == 4 and 0 < m["frac_of_fp4_peak"] < m["frac_of_i8_peak"] < 1
+    assert one["roofline"]["hbm_copy_measured"]["GBps"] > 1000 and one["roofline"]["hbm_copy_measured"]["lut_pass"]["GBps"] > 1000
 
 
 def test_bench_under_torch_distributed_run():
