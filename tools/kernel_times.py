@@ -10,7 +10,7 @@ reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 H, W = (2160, 3840) if os.environ.get("KT_4K") else (1080, 1920)
 base = synth.uw_stream(0, min(F, 16), H, W)
 src = torch.from_numpy(np.concatenate([base] * ((F + len(base) - 1) // len(base)))[:F]).cuda()
-pipe = FramePipe(0, F, H, W)
+pipe = FramePipe(0, F, H, W, guard_s=True)
 pipe.run(src); torch.cuda.synchronize()
 pipe.ctx.prof_reset(); pipe.ctx.prof_enable(True)
 for _ in range(reps):

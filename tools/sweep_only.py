@@ -5,7 +5,7 @@ import torch
 from uwimageproc_amd import aclahe, synth
 from uwimageproc_amd.pipeline import FramePipe
 F, H, W = 32, 1080, 1920
-pipe = FramePipe(0, F, H, W)
+pipe = FramePipe(0, F, H, W, guard_s=True)
 import numpy as np
 base = synth.uw_stream(0, 8, H, W)
 src = torch.from_numpy(np.concatenate([base] * 4)).cuda()

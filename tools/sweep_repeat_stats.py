@@ -7,7 +7,7 @@ import torch
 from uwimageproc_amd import aclahe, synth
 from uwimageproc_amd.pipeline import FramePipe
 F, H, W = (2, 2160, 3840) if os.environ.get("STATS_4K") else (8, 1080, 1920)
-pipe = FramePipe(0, F, H, W)
+pipe = FramePipe(0, F, H, W, guard_s=True)
 src = torch.from_numpy(synth.uw_stream(0, F, H, W)).cuda()
 pipe.stage_dehaze(src); pipe.stage_histretch()
 v = aclahe.GaussianBlur3(pipe.ctx, aclahe.bgr_to_v(pipe.ctx, pipe.work)).cpu().numpy()

@@ -11,7 +11,7 @@ from uwimageproc_amd import aclahe, synth
 from uwimageproc_amd.pipeline import FramePipe
 
 F, H, W = 2, 1080, 1920
-pipe = FramePipe(0, F, H, W)
+pipe = FramePipe(0, F, H, W, guard_s=True)
 src = torch.from_numpy(synth.uw_stream_motion(0, F, H, W) if hasattr(synth, "uw_stream_motion") else synth.uw_stream(0, F, H, W)).cuda()
 pipe.stage_dehaze(src); pipe.stage_histretch()
 v = aclahe.GaussianBlur3(pipe.ctx, aclahe.bgr_to_v(pipe.ctx, pipe.work)).cpu().numpy()

@@ -46,6 +46,11 @@ __global__ __launch_bounds__(256) void k(float *out, const float *in, int iters,
         if (OP == 37) { REP8(asm volatile("v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(ua));) }
         if (OP == 38) { REP8(asm volatile("v_mul_u32_u24 %0, %0, %8\n v_mul_u32_u24 %1, %1, %8\n v_mul_u32_u24 %2, %2, %8\n v_mul_u32_u24 %3, %3, %8\n v_mul_u32_u24 %4, %4, %8\n v_mul_u32_u24 %5, %5, %8\n v_mul_u32_u24 %6, %6, %8\n v_mul_u32_u24 %7, %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(ua));) }
         if (OP == 39) { REP8(asm volatile("v_add_u32_dpp %0, %8, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %1, %8, %1 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %2, %8, %2 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %3, %8, %3 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %4, %8, %4 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %5, %8, %5 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %6, %8, %6 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0\n v_add_u32_dpp %7, %8, %7 row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(ua));) }
+        // round 5: the integer-weight form of the sweep's evaluation (priced in DESIGN.md section 5)
+        if (OP == 40) { REP8(asm volatile("v_dot4_u32_u8 %0, %8, %9, %0\n v_dot4_u32_u8 %1, %8, %9, %1\n v_dot4_u32_u8 %2, %8, %9, %2\n v_dot4_u32_u8 %3, %8, %9, %3\n v_dot4_u32_u8 %4, %8, %9, %4\n v_dot4_u32_u8 %5, %8, %9, %5\n v_dot4_u32_u8 %6, %8, %9, %6\n v_dot4_u32_u8 %7, %8, %9, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(ua), "v"(b));) }
+        if (OP == 41) { REP8(asm volatile("v_lshrrev_b32 %0, 3, %0\n v_lshrrev_b32 %1, 3, %1\n v_lshrrev_b32 %2, 3, %2\n v_lshrrev_b32 %3, 3, %3\n v_lshrrev_b32 %4, 3, %4\n v_lshrrev_b32 %5, 3, %5\n v_lshrrev_b32 %6, 3, %6\n v_lshrrev_b32 %7, 3, %7" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));) }
+        if (OP == 42) { REP8(asm volatile("v_cmp_eq_u32 vcc, %0, %8\n v_cmp_eq_u32 vcc, %1, %8\n v_cmp_eq_u32 vcc, %2, %8\n v_cmp_eq_u32 vcc, %3, %8\n v_cmp_eq_u32 vcc, %4, %8\n v_cmp_eq_u32 vcc, %5, %8\n v_cmp_eq_u32 vcc, %6, %8\n v_cmp_eq_u32 vcc, %7, %8" :: "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "v"(ua) : "vcc");) }
+        if (OP == 43) { REP8(asm volatile("v_cvt_u32_f32 %0, %8\n v_cvt_u32_f32 %1, %8\n v_cvt_u32_f32 %2, %8\n v_cvt_u32_f32 %3, %8\n v_cvt_u32_f32 %4, %8\n v_cvt_u32_f32 %5, %8\n v_cvt_u32_f32 %6, %8\n v_cvt_u32_f32 %7, %8" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));) }
         // LDS: 20 ds_read_b32, 23 ds_read_b64, 24 ds_read_b128, 21/22/25 ds_add_u32 (same word / same bank / linear)
         if (OP == 20) { REP8(asm volatile("ds_read_b32 %0, %8\n ds_read_b32 %1, %8 offset:256\n ds_read_b32 %2, %8 offset:512\n ds_read_b32 %3, %8 offset:768\n ds_read_b32 %4, %8 offset:1024\n ds_read_b32 %5, %8 offset:1280\n ds_read_b32 %6, %8 offset:1536\n ds_read_b32 %7, %8 offset:1792\n s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(addr));) }
         if (OP == 23) { REP8(asm volatile("ds_read_b64 %0, %4\n ds_read_b64 %1, %4 offset:2048\n ds_read_b64 %2, %4 offset:4096\n ds_read_b64 %3, %4 offset:6144\n ds_read_b64 %0, %4 offset:8192\n ds_read_b64 %1, %4 offset:10240\n ds_read_b64 %2, %4 offset:12288\n ds_read_b64 %3, %4 offset:14336\n s_waitcnt lgkmcnt(0)" : "+v"(*(double*)&a0), "+v"(*(double*)&a2), "+v"(*(double*)&a4), "+v"(*(double*)&a6) : "v"(addr * 2));) }
@@ -88,6 +93,12 @@ int main()
     for (int w : {1, 2}) {
         run<30>("v_fma_f64", w); run<31>("v_add_f64", w); run<32>("v_mul_f64", w); run<33>("v_rcp_f64", w); run<34>("v_cvt_f64_u32", w);
         run<35>("v_mov_b32_dpp", w); run<39>("v_add_u32_dpp", w); run<36>("v_add_u32", w); run<37>("v_mov_b32", w); run<38>("v_mul_u32_u24", w);
+        printf("\n");
+    }
+    if (getenv("UB_INT"))
+    for (int w : {2, 4, 6}) {
+        run<40>("v_dot4_u32_u8", w); run<41>("v_lshrrev_b32", w); run<42>("v_cmp_eq_u32", w); run<43>("v_cvt_u32_f32", w); run<7>("v_lshl_add_u32", w);
+        run<10>("v_and_b32", w); run<1>("v_mul_f32", w); run<4>("v_cvt_f32_ubyteN", w); run<8>("v_perm_b32", w);
         printf("\n");
     }
     if (getenv("UB_ALL"))
