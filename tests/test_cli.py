@@ -437,3 +437,34 @@ def test_uwpipe_cli_whole_chain_over_the_c_pipe(tmp_path, orc):
         assert (int(rows[i][3]), int(rows[i][4])) == tuple(exp_par[i]), i
     er, _, _ = orc.calcOverlap(got[0], got[1], W, H, seed=1)
     assert abs(float(rows[1][2]) - er) <= 1e-5
+    # the same frames as a Motion-JPEG .avi with the three opt-in switches: the tool sees the DECODED JPEGs, so the expectation is
+    # the Python caller of the same C entry on those, with the same flags (guard_s, min6; relative threshold via the config)
+    import io
+    import ctypes as C
+    jpegs, dec = [], []
+    for f in frames:
+        buf = io.BytesIO()
+        Image.fromarray(np.ascontiguousarray(f[..., ::-1])).save(buf, format="JPEG", quality=92, subsampling=2)
+        jpegs.append(buf.getvalue())
+        dec.append(np.ascontiguousarray(np.asarray(Image.open(io.BytesIO(buf.getvalue())).convert("RGB"))[..., ::-1]))
+    dec = np.stack(dec)
+    avi = str(tmp_path / "clip.avi")
+    _write_mjpeg_avi(avi, jpegs, 25.0, W, H)
+    prefix2 = str(tmp_path / "avi_")
+    r = subprocess.run([os.path.join(BIN, "uwpipe"), "-b", str(B), "--png", "--guard-s", "--min6", "--relative-threshold", avi, prefix2],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows2 = [l.split("\t") for l in open(prefix2 + "uwpipe_report.txt").read().splitlines() if l[:1].isdigit()]
+    pipe = FramePipe(0, B, H, W, guard_s=True, min6=True)
+    pipe._cfg.detect_flags = 16                               # UWIP_OVERLAP_RELATIVE_THRESHOLD
+    pipe._l.uwip_pipe_destroy(pipe._p); pipe._create()
+    for k in range((n + B - 1) // B):
+        idx = [min(k * B + j, n - 1) for j in range(B)]
+        out, ratio = pipe.run(torch.from_numpy(dec[idx]).cuda())
+        torch.cuda.synchronize()
+        for j in range(B):
+            i = k * B + j
+            if i < n:
+                assert np.array_equal(_load_png(f"{prefix2}{i:04d}.png"), out[j].cpu().numpy()), i
+                assert abs(float(rows2[i][2]) - float(ratio[j])) <= 1e-5 * max(1.0, abs(float(ratio[j]))), (i, rows2[i])
+    pipe.close()
