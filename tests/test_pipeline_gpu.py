@@ -305,7 +305,8 @@ def test_stream_driver_seam_rule_with_the_real_pipe():
         assert np.array_equal(got_o[i], o1[i]), i
 
 
-def test_pipe_c_abi_reference_defaults_step_and_host_form(orc):
+@pytest.mark.parametrize("shape", [(270, 480), (275, 483)])
+def test_pipe_c_abi_reference_defaults_step_and_host_form(orc, shape):
     """uwip_pipe_* driven through ctypes alone (what a C / C++ integrator binds, include/uwip.h "the whole per-frame chain"):
     with uwip_pipe_config_default -- the reference's rules: S unguarded, >= 4 good matches, fixed detector threshold -- two
     steps through uwip_pipe_step equal the chain made by hand from the stage entry points (uwip_dehaze_histretch, uwip_bgr_to_v,
@@ -313,7 +314,7 @@ def test_pipe_c_abi_reference_defaults_step_and_host_form(orc):
     batches through uwip_pipe_step_host (frames AND ratios downloaded, tickets) give the same bytes."""
     import ctypes as C
     from uwimageproc_amd import Context, PipeConfig, batch_of
-    F, H, W = 3, 270, 480
+    F, (H, W) = 3, shape              # 275 x 483: rows of 1449 bytes -- every kernel of the chain on its unaligned / scalar path
     ctx = Context(0)
     l = ctx._l
     cfg = PipeConfig()
