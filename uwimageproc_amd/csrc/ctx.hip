@@ -5,7 +5,7 @@
 #include <algorithm>
 #include <ctime>
 
-UWIP_API const char *uwip_version(void) { return "uwip-mi355x 0.1 (gfx950)"; }
+UWIP_API const char *uwip_version(void) { return "uwip-mi355x 0.5 (gfx950)"; }
 
 UWIP_API int uwip_device_count(int *count)
 {
